@@ -1,0 +1,164 @@
+/*
+ * ivfhnsw_hip.h -- C ABI of the MI355X (gfx950) IVFADC search path.
+ *
+ * This is the drop-in boundary: the reference (uniio/ivf-hnsw, C++11, CPU only) has no FFI of its
+ * own, so every entry point below cites the reference interface it replaces (file:line relative to
+ * the reference tree).  The host-side mirror of the reference classes (the headers under include/ivf-hnsw/,
+ * ivf-hnsw_amd/csrc/host/) calls nothing but these functions; INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain C, opaque handle, int status (0 = ok, negative = error, message through
+ * ivfhnsw_gpu_last_error()), no exceptions cross the boundary, host pointers passed to upload_*
+ * are copied and never retained.  There is no CPU fallback: every call fails with
+ * IVFHNSW_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef IVFHNSW_HIP_H
+#define IVFHNSW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IVFHNSW_OK 0
+#define IVFHNSW_ERR_INVALID (-1) /* bad argument / shape mismatch */
+#define IVFHNSW_ERR_HIP (-2)     /* HIP runtime error, or no device */
+#define IVFHNSW_ERR_STATE (-3)   /* call order: something required was not uploaded */
+#define IVFHNSW_ERR_NOMEM (-4)
+
+typedef struct ivfhnsw_gpu ivfhnsw_gpu;
+
+/* Thread-local message of the last failing call on this thread. */
+const char *ivfhnsw_gpu_last_error(void);
+
+/* ABI version of this header (bumped on any signature change). */
+int ivfhnsw_gpu_abi_version(void);
+
+/* IndexIVF_HNSW::IndexIVF_HNSW / ~IndexIVF_HNSW (IndexIVF_HNSW.cpp:8-32): device-side state of one
+ * index.  `device` is the HIP device ordinal. */
+int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out);
+int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h);
+
+/* Optional: run on a caller-owned hipStream_t (passed as void*) instead of the handle's own stream. */
+int ivfhnsw_gpu_set_stream(ivfhnsw_gpu *h, void *hip_stream);
+/* Block until everything queued on the handle's stream has finished. */
+int ivfhnsw_gpu_sync(ivfhnsw_gpu *h);
+
+/* The inverted lists and the quantizer tables: the data members of IndexIVF_HNSW
+ * (IndexIVF_HNSW.h:50-66,81) after read() (IndexIVF_HNSW.cpp:758-779), flattened to CSR.
+ * list c occupies [offsets[c], offsets[c+1]) of ids / norm_codes and code_size times that of codes,
+ * in list order (the scan order decides ties, IndexIVF_HNSW.cpp:285).
+ *
+ * Sharding: with shard_world > 1 the arrays ids/codes/norm_codes hold only the lists
+ * with c % shard_world == shard_rank, concatenated in increasing c; offsets is always the global
+ * table, so every shard derives the same scan plan. */
+typedef struct ivfhnsw_ivf_desc {
+    size_t d;                    /* IndexIVF_HNSW.h:50 */
+    size_t nc;                   /* :51 */
+    size_t code_size;            /* :52; multiple of 4 (IndexIVF_HNSW.cpp:805) */
+    const uint64_t *offsets;     /* [nc+1] */
+    const uint32_t *ids;         /* :64 */
+    const uint8_t *codes;        /* :65 */
+    const uint8_t *norm_codes;   /* :66 */
+    const float *centroid_norms; /* :81, [nc] */
+    const float *pq_centroids;   /* pq->centroids, [code_size][256][d/code_size] (:56) */
+    const float *norm_table;     /* norm_pq->centroids, [256] (:57) */
+    const float *opq_A;          /* opq_matrix->A, [d][d] row major, or NULL when !do_opq (:58-59) */
+    uint32_t shard_rank, shard_world; /* 0, 1 for a single GPU */
+} ivfhnsw_ivf_desc;
+int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *desc);
+
+/* Same tables, but codes / norm codes are generated on the device (uniform bytes from `seed`) and
+ * ids are the running index: the SIFT1B-shaped synthetic corpus of SURVEY 8d for sizes that never
+ * exist on the host.  desc->ids/codes/norm_codes are ignored. */
+int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *desc, uint64_t seed);
+
+/* The extra members of IndexIVF_HNSW_Grouping (IndexIVF_HNSW_Grouping.h:17-22,61) after read()
+ * (IndexIVF_HNSW_Grouping.cpp:445-483).  All [nc*nsubc] row major; subgroup_sizes rows of empty
+ * groups are zero.  Requires upload_ivf first and upload_quantizer before searching. */
+int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alphas,
+                                const uint32_t *nn_centroid_idxs, const uint32_t *subgroup_sizes,
+                                const float *inter_centroid_dists);
+
+/* The coarse quantizer: hnswlib::HierarchicalNSW node storage (hnswlib/hnswalg.h:47-82; link count,
+ * maxM link slots and d floats per node, hnswalg.cpp:25-27) as three arrays.  `vectors` are the
+ * centroids as the graph holds them at search time, i.e. after rotate_quantizer()
+ * (IndexIVF_HNSW.cpp:789-800) when OPQ is on.  Needed for Grouping (sub-centroid distances,
+ * IndexIVF_HNSW_Grouping.cpp:248,314) and for the on-device coarse walk. */
+int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
+                                 const uint8_t *link_counts, const uint32_t *links, const float *vectors);
+
+/* The search-time knobs the drivers set as public members (IndexIVF_HNSW.h:61-62, hnswalg.h:69,
+ * IndexIVF_HNSW_Grouping.h:18). */
+typedef struct ivfhnsw_search_params {
+    size_t nprobe;
+    size_t max_codes;
+    size_t efSearch;
+    int do_pruning;
+} ivfhnsw_search_params;
+
+/* IndexIVF_HNSW::search / IndexIVF_HNSW_Grouping::search (IndexIVF_HNSW.cpp:234-296,
+ * IndexIVF_HNSW_Grouping.cpp:188-363) for nq queries at once.  All pointers are HOST memory.
+ *
+ * coarse_ids / coarse_dists ([nq*nprobe], nearest first) are the result of the coarse stage when the
+ * caller ran it, exactly IndexIVF_HNSW::search2 (IndexIVF_HNSW.cpp:453-492); coarse slots holding
+ * 0xffffffff are skipped.  Pass NULL for both to run the HNSW walk (hnswalg.cpp:48-109,227-234) on
+ * the device; that needs upload_quantizer and efSearch >= nprobe.
+ *
+ * Results: distances[nq*k], labels[nq*k] (int64, the reference's `long`), ascending by
+ * (distance, scan position); unfilled slots hold FLT_MAX / -1 as after faiss::maxheap_heapify.
+ * For k = 1 (every preset of the reference) this is exactly the reference's output; for k > 1 it is
+ * the same set, sorted, where the reference leaves heap-array order. */
+int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries, const uint32_t *coarse_ids,
+                       const float *coarse_dists, const ivfhnsw_search_params *params, float *distances,
+                       int64_t *labels);
+
+/* Same, with every buffer already resident in HBM (device pointers), asynchronous on the handle's
+ * stream.  out_keys (nullable, [nq*k] int64) receives the packed (orderable distance << 32 | scan
+ * position) keys, sign-flipped so that a plain signed int64 MIN over the shards (RCCL all-reduce) picks
+ * the reference's winner: smallest distance, earliest scan position on ties. */
+int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries,
+                           const uint32_t *d_coarse_ids, const float *d_coarse_dists,
+                           const ivfhnsw_search_params *params, float *d_distances, int64_t *d_labels,
+                           int64_t *d_out_keys);
+
+/* Multi-GPU merge helper: given keys already MIN-reduced over the shards, resolve the
+ * labels this shard owns ([nq*k]; -1 where the winner lives on another shard) from the scan plan of
+ * the last search_dev call, and decode the distances.  The caller then MAX-reduces the labels. */
+int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *d_keys,
+                                 float *d_distances, int64_t *d_labels);
+
+/* The coarse stage alone (HierarchicalNSW::searchKnn, hnswalg.cpp:227-234, plus the unload loop of
+ * IndexIVF_HNSW.cpp:249-259): device pointers, [nq*nprobe] outputs, nearest first.  Queries must
+ * already be rotated when OPQ is on. */
+int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, size_t nprobe, size_t efSearch,
+                           uint32_t *d_coarse_ids, float *d_coarse_dists);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+
+enum ivfhnsw_stage {
+    IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */
+    IVFHNSW_STAGE_COARSE = 1, /* quantizer->searchKnn, :248 */
+    IVFHNSW_STAGE_LUT = 2,    /* pq->compute_inner_prod_table, :262 */
+    IVFHNSW_STAGE_PLAN = 3,   /* probe order + max_codes rule, :267-292 / Grouping.cpp:222-262 */
+    IVFHNSW_STAGE_SCAN = 4,   /* the ADC loop, :282-289 */
+    IVFHNSW_STAGE_SELECT = 5, /* label resolution */
+    IVFHNSW_STAGE_COUNT = 6
+};
+/* With profiling on, every search brackets each stage with hipEvents on the launch stream. */
+int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled);
+/* Accumulated since the last reset: milliseconds and number of launches of one stage. */
+int ivfhnsw_gpu_get_stage_ms(ivfhnsw_gpu *h, int stage, double *ms_total, uint64_t *launches);
+int ivfhnsw_gpu_reset_stage_ms(ivfhnsw_gpu *h);
+/* Accounting of the last search on this handle: codes scored by this shard (the reference's `ncode`,
+ * IndexIVF_HNSW.cpp:290, summed over the batch) and (sub)lists scored.  Synchronises. */
+int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nsegments);
+/* Bytes of HBM currently held by the handle. */
+int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""ctypes binding of libivfhnsw_hip.so (include/ivfhnsw_hip.h) for the tests and bench.py.
+
+The product is the shared library; this module adds nothing but argument marshalling.  There is no
+fallback of any kind: if the library is missing or no gfx950 device is present, calls raise.
+
+The directory name has a hyphen (it mirrors the reference's name), so it is loaded through
+`__graft_entry__.load_pkg()` rather than a plain import.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libivfhnsw_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
+STAGES = ("opq", "coarse", "lut", "plan", "scan", "select")
+
+# every symbol include/ivfhnsw_hip.h declares
+ABI_SYMBOLS = (
+    "ivfhnsw_gpu_last_error", "ivfhnsw_gpu_abi_version", "ivfhnsw_gpu_create", "ivfhnsw_gpu_destroy",
+    "ivfhnsw_gpu_set_stream", "ivfhnsw_gpu_sync", "ivfhnsw_gpu_upload_ivf", "ivfhnsw_gpu_upload_ivf_synthetic",
+    "ivfhnsw_gpu_upload_grouping", "ivfhnsw_gpu_upload_quantizer", "ivfhnsw_gpu_search", "ivfhnsw_gpu_search_dev",
+    "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_set_profiling",
+    "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
+    "ivfhnsw_gpu_memory_bytes",
+)
+
+
+class IvfDesc(C.Structure):
+    _fields_ = [("d", C.c_size_t), ("nc", C.c_size_t), ("code_size", C.c_size_t),
+                ("offsets", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p),
+                ("norm_codes", C.c_void_p), ("centroid_norms", C.c_void_p), ("pq_centroids", C.c_void_p),
+                ("norm_table", C.c_void_p), ("opq_A", C.c_void_p),
+                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("nprobe", C.c_size_t), ("max_codes", C.c_size_t), ("efSearch", C.c_size_t),
+                ("do_pruning", C.c_int)]
+
+
+class IvfHnswError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ivfhnsw_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library (once).  Raises if it has not been built: there is no other path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run __graft_entry__.build() (make -C ivf-hnsw_amd/csrc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.ivfhnsw_gpu_last_error.restype = C.c_char_p
+        L.ivfhnsw_gpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.ivfhnsw_gpu_destroy.argtypes = [C.c_void_p]
+        L.ivfhnsw_gpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_sync.argtypes = [C.c_void_p]
+        L.ivfhnsw_gpu_upload_ivf.argtypes = [C.c_void_p, C.POINTER(IvfDesc)]
+        L.ivfhnsw_gpu_upload_ivf_synthetic.argtypes = [C.c_void_p, C.POINTER(IvfDesc), C.c_uint64]
+        L.ivfhnsw_gpu_upload_grouping.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+        L.ivfhnsw_gpu_upload_quantizer.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_search.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(SearchParams), C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_search_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(SearchParams), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_resolve_keys_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
+        L.ivfhnsw_gpu_coarse_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                             C.c_void_p]
+        L.ivfhnsw_gpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.ivfhnsw_gpu_get_stage_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
+        L.ivfhnsw_gpu_last_scan_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ivfhnsw_gpu_memory_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise IvfHnswError(rc, lib().ivfhnsw_gpu_last_error().decode())
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _devptr(t):
+    """Device pointer of a torch tensor (or a raw int address / None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+class GpuIndex:
+    """One device-side index (ivfhnsw_gpu handle)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(lib().ivfhnsw_gpu_create(device, C.byref(self._h)))
+        self.d = self.nc = self.code_size = 0
+
+    def close(self):
+        if self._h:
+            lib().ivfhnsw_gpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- uploads -------------------------------------------------------------------------------
+    def _desc(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, ids, codes, norm_codes,
+              shard_rank, shard_world):
+        keep = {}
+        keep["offsets"] = _np(offsets, np.uint64)
+        nc = len(keep["offsets"]) - 1
+        keep["centroid_norms"] = _np(centroid_norms, np.float32)
+        keep["pq_centroids"] = _np(pq_centroids, np.float32)
+        keep["norm_table"] = _np(norm_table, np.float32)
+        assert keep["centroid_norms"].size == nc
+        assert keep["pq_centroids"].size == 256 * d
+        assert keep["norm_table"].size == 256
+        keep["opq_A"] = None if opq_A is None else _np(opq_A, np.float32)
+        keep["ids"] = None if ids is None else _np(ids, np.uint32)
+        keep["codes"] = None if codes is None else _np(codes, np.uint8)
+        keep["norm_codes"] = None if norm_codes is None else _np(norm_codes, np.uint8)
+        desc = IvfDesc(d, nc, code_size, _ptr(keep["offsets"]), _ptr(keep["ids"]), _ptr(keep["codes"]),
+                       _ptr(keep["norm_codes"]), _ptr(keep["centroid_norms"]), _ptr(keep["pq_centroids"]),
+                       _ptr(keep["norm_table"]), _ptr(keep["opq_A"]), shard_rank, shard_world)
+        self.d, self.nc, self.code_size = d, nc, code_size
+        return desc, keep
+
+    def upload_ivf(self, d, code_size, offsets, ids, codes, norm_codes, centroid_norms, pq_centroids, norm_table,
+                   opq_A=None, shard_rank=0, shard_world=1):
+        desc, keep = self._desc(d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, ids, codes,
+                                norm_codes, shard_rank, shard_world)
+        _check(lib().ivfhnsw_gpu_upload_ivf(self._h, C.byref(desc)))
+
+    def upload_ivf_synthetic(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, seed, opq_A=None):
+        desc, keep = self._desc(d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, None, None,
+                                None, 0, 1)
+        _check(lib().ivfhnsw_gpu_upload_ivf_synthetic(self._h, C.byref(desc), seed))
+
+    def upload_grouping(self, nsubc, alphas, nn_centroid_idxs, subgroup_sizes, inter_centroid_dists):
+        a = _np(alphas, np.float32)
+        n = _np(nn_centroid_idxs, np.uint32)
+        s = _np(subgroup_sizes, np.uint32)
+        i = _np(inter_centroid_dists, np.float32)
+        assert a.size == self.nc and n.size == s.size == i.size == self.nc * nsubc
+        _check(lib().ivfhnsw_gpu_upload_grouping(self._h, nsubc, _ptr(a), _ptr(n), _ptr(s), _ptr(i)))
+
+    def upload_quantizer(self, link_counts, links, vectors, enterpoint=0):
+        c = _np(link_counts, np.uint8)
+        v = _np(vectors, np.float32)
+        n, d = v.shape
+        l = _np(links, np.uint32).reshape(n, -1)
+        _check(lib().ivfhnsw_gpu_upload_quantizer(self._h, n, d, l.shape[1], enterpoint, _ptr(c), _ptr(l), _ptr(v)))
+
+    # ---- search --------------------------------------------------------------------------------
+    @staticmethod
+    def _params(nprobe, max_codes, efSearch, do_pruning):
+        return SearchParams(nprobe, max_codes, efSearch, 1 if do_pruning else 0)
+
+    def search(self, queries, k, nprobe, max_codes, coarse_ids=None, coarse_dists=None, efSearch=0,
+               do_pruning=False):
+        """Host arrays in, host arrays out (ivfhnsw_gpu_search)."""
+        q = _np(queries, np.float32).reshape(-1, self.d)
+        nq = q.shape[0]
+        cid = None if coarse_ids is None else _np(coarse_ids, np.uint32).reshape(nq, nprobe)
+        cd = None if coarse_dists is None else _np(coarse_dists, np.float32).reshape(nq, nprobe)
+        dist = np.empty((nq, k), np.float32)
+        lab = np.empty((nq, k), np.int64)
+        p = self._params(nprobe, max_codes, efSearch, do_pruning)
+        _check(lib().ivfhnsw_gpu_search(self._h, nq, k, _ptr(q), _ptr(cid), _ptr(cd), C.byref(p), _ptr(dist),
+                                        _ptr(lab)))
+        return dist, lab
+
+    def search_dev(self, nq, k, d_queries, d_distances, d_labels, nprobe, max_codes, d_coarse_ids=None,
+                   d_coarse_dists=None, efSearch=0, do_pruning=False, d_out_keys=None):
+        """Device buffers (torch CUDA tensors), asynchronous on the handle's stream."""
+        p = self._params(nprobe, max_codes, efSearch, do_pruning)
+        _check(lib().ivfhnsw_gpu_search_dev(self._h, nq, k, _devptr(d_queries), _devptr(d_coarse_ids),
+                                            _devptr(d_coarse_dists), C.byref(p), _devptr(d_distances),
+                                            _devptr(d_labels), _devptr(d_out_keys)))
+
+    def resolve_keys_dev(self, nq, k, d_keys, d_distances, d_labels):
+        _check(lib().ivfhnsw_gpu_resolve_keys_dev(self._h, nq, k, _devptr(d_keys), _devptr(d_distances),
+                                                  _devptr(d_labels)))
+
+    def coarse_dev(self, nq, d_queries, nprobe, efSearch, d_coarse_ids, d_coarse_dists):
+        _check(lib().ivfhnsw_gpu_coarse_dev(self._h, nq, _devptr(d_queries), nprobe, efSearch,
+                                            _devptr(d_coarse_ids), _devptr(d_coarse_dists)))
+
+    def sync(self):
+        _check(lib().ivfhnsw_gpu_sync(self._h))
+
+    def set_stream(self, stream_ptr):
+        _check(lib().ivfhnsw_gpu_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- measurement ---------------------------------------------------------------------------
+    def set_profiling(self, on):
+        _check(lib().ivfhnsw_gpu_set_profiling(self._h, 1 if on else 0))
+
+    def reset_stage_ms(self):
+        _check(lib().ivfhnsw_gpu_reset_stage_ms(self._h))
+
+    def stage_ms(self):
+        out = {}
+        for i, name in enumerate(STAGES):
+            ms, n = C.c_double(), C.c_uint64()
+            _check(lib().ivfhnsw_gpu_get_stage_ms(self._h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def last_scan_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().ivfhnsw_gpu_last_scan_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def memory_bytes(self):
+        a = C.c_uint64()
+        _check(lib().ivfhnsw_gpu_memory_bytes(self._h, C.byref(a)))
+        return a.value

@@ -1,0 +1,747 @@
+// C ABI of the gfx950 IVFADC search path (include/ivfhnsw_hip.h): device state, uploads, the
+// batched search pipeline (rotate -> coarse -> table -> plan -> scan -> select) and its measurement.
+#include "../../include/ivfhnsw_hip.h"
+#include "ivfhnsw_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ivfhnsw_gpu_impl;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? IVFHNSW_ERR_NOMEM : IVFHNSW_ERR_HIP, "%s: %s (%s:%d)",   \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                   \
+    } while (0)
+
+// A device allocation that only ever grows.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes)
+            return IVFHNSW_OK;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipMalloc(&p, need ? need : 1));
+        bytes = need;
+        return IVFHNSW_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct StageEvent {
+    int stage;
+    hipEvent_t a, b;
+};
+
+} // namespace
+
+struct ivfhnsw_gpu {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // index tables
+    DevBuf goff, loff, cnorm, pqc, ntab, opq_at, codes, ncodes, ids;
+    IvfTables t{};
+    bool has_ivf = false;
+    uint64_t n_local = 0;
+    DevBuf g_alpha, g_nn, g_sizes, g_inter;
+    GroupTables g{};
+    bool has_group = false;
+    DevBuf q_counts, q_links, q_vectors;
+    GraphTables gr{};
+    bool has_graph = false;
+
+    // per-batch workspace
+    DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited;
+    // staging for the host-pointer entry point
+    DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
+
+    int last_nq = 0, last_max_seg = 0;
+
+    bool profiling = false;
+    std::vector<StageEvent> pending;
+    std::vector<hipEvent_t> pool;
+    double stage_ms[IVFHNSW_STAGE_COUNT] = {0};
+    uint64_t stage_n[IVFHNSW_STAGE_COUNT] = {0};
+};
+
+namespace {
+
+int bind(ivfhnsw_gpu *h)
+{
+    if (!h)
+        return fail(IVFHNSW_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return IVFHNSW_OK;
+}
+
+int upload(DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = b.ensure(bytes);
+    if (rc)
+        return rc;
+    if (bytes)
+        HIP_TRY(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return IVFHNSW_OK;
+}
+
+hipEvent_t take_event(ivfhnsw_gpu *h)
+{
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageScope {
+    ivfhnsw_gpu *h;
+    StageEvent ev{};
+    bool on;
+    StageScope(ivfhnsw_gpu *h_, int stage) : h(h_), on(h_->profiling)
+    {
+        if (!on)
+            return;
+        ev.stage = stage;
+        ev.a = take_event(h);
+        ev.b = take_event(h);
+        (void)hipEventRecord(ev.a, h->stream);
+    }
+    ~StageScope()
+    {
+        if (!on)
+            return;
+        (void)hipEventRecord(ev.b, h->stream);
+        h->pending.push_back(ev);
+    }
+};
+
+int drain_events(ivfhnsw_gpu *h)
+{
+    for (auto &ev : h->pending) {
+        HIP_TRY(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        h->stage_ms[ev.stage] += ms;
+        h->stage_n[ev.stage] += 1;
+        h->pool.push_back(ev.a);
+        h->pool.push_back(ev.b);
+    }
+    h->pending.clear();
+    return IVFHNSW_OK;
+}
+
+int check_desc(const ivfhnsw_ivf_desc *d, bool need_lists)
+{
+    if (!d)
+        return fail(IVFHNSW_ERR_INVALID, "null descriptor");
+    if (d->d == 0 || d->nc == 0 || d->code_size == 0)
+        return fail(IVFHNSW_ERR_INVALID, "d, nc and code_size must be positive");
+    if (d->code_size % 4)
+        return fail(IVFHNSW_ERR_INVALID, "code_size %zu is not a multiple of 4 (IndexIVF_HNSW.cpp:805)", d->code_size);
+    if (d->code_size != 4 && d->code_size != 8 && d->code_size != 16 && d->code_size != 32)
+        return fail(IVFHNSW_ERR_INVALID, "code_size %zu unsupported (4, 8, 16, 32)", d->code_size);
+    if (d->d % d->code_size)
+        return fail(IVFHNSW_ERR_INVALID, "d %zu is not a multiple of code_size %zu", d->d, d->code_size);
+    if (d->d / d->code_size > 64)
+        return fail(IVFHNSW_ERR_INVALID, "sub-vector dimension %zu > 64 unsupported", d->d / d->code_size);
+    if (d->nc >= 0xffffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "nc too large");
+    if (!d->offsets || !d->centroid_norms || !d->pq_centroids || !d->norm_table)
+        return fail(IVFHNSW_ERR_INVALID, "offsets, centroid_norms, pq_centroids and norm_table are required");
+    if (need_lists && (!d->ids || !d->codes || !d->norm_codes))
+        return fail(IVFHNSW_ERR_INVALID, "ids, codes and norm_codes are required");
+    if (d->shard_world == 0 || d->shard_rank >= d->shard_world)
+        return fail(IVFHNSW_ERR_INVALID, "bad shard %u of %u", d->shard_rank, d->shard_world);
+    if (d->offsets[0] != 0)
+        return fail(IVFHNSW_ERR_INVALID, "offsets[0] must be 0");
+    for (size_t c = 0; c < d->nc; c++)
+        if (d->offsets[c + 1] < d->offsets[c])
+            return fail(IVFHNSW_ERR_INVALID, "offsets not monotone at list %zu", c);
+    return IVFHNSW_OK;
+}
+
+// Tables shared by upload_ivf and upload_ivf_synthetic; fills h->t except codes/norm_codes/ids.
+int upload_tables(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, std::vector<uint32_t> &loff, uint64_t &n_local)
+{
+    loff.assign(d->nc, 0);
+    n_local = 0;
+    for (size_t c = 0; c < d->nc; c++) {
+        if (c % d->shard_world != d->shard_rank)
+            continue;
+        if (n_local > 0xffffffffull)
+            return fail(IVFHNSW_ERR_INVALID, "more than 2^32 codes on one shard");
+        loff[c] = (uint32_t)n_local;
+        n_local += d->offsets[c + 1] - d->offsets[c];
+    }
+    if (n_local > 0xffffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "more than 2^32 codes on one shard");
+    int rc;
+    if ((rc = upload(h->goff, d->offsets, (d->nc + 1) * sizeof(uint64_t))))
+        return rc;
+    if ((rc = upload(h->loff, loff.data(), d->nc * sizeof(uint32_t))))
+        return rc;
+    if ((rc = upload(h->cnorm, d->centroid_norms, d->nc * sizeof(float))))
+        return rc;
+    if ((rc = upload(h->pqc, d->pq_centroids, 256 * d->d * sizeof(float))))
+        return rc;
+    if ((rc = upload(h->ntab, d->norm_table, 256 * sizeof(float))))
+        return rc;
+    if (d->opq_A) {
+        std::vector<float> at(d->d * d->d);
+        for (size_t i = 0; i < d->d; i++)
+            for (size_t k = 0; k < d->d; k++)
+                at[k * d->d + i] = d->opq_A[i * d->d + k];
+        if ((rc = upload(h->opq_at, at.data(), at.size() * sizeof(float))))
+            return rc;
+    } else {
+        h->opq_at.release();
+    }
+    IvfTables &t = h->t;
+    t.d = (int)d->d;
+    t.M = (int)d->code_size;
+    t.dsub = (int)(d->d / d->code_size);
+    t.nc = (uint32_t)d->nc;
+    t.goff = h->goff.as<uint64_t>();
+    t.loff = h->loff.as<uint32_t>();
+    t.centroid_norms = h->cnorm.as<float>();
+    t.pq_centroids = h->pqc.as<float>();
+    t.norm_table = h->ntab.as<float>();
+    t.opq_At = d->opq_A ? h->opq_at.as<float>() : nullptr;
+    t.shard_rank = d->shard_rank;
+    t.shard_world = d->shard_world;
+    return IVFHNSW_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
+
+int ivfhnsw_gpu_abi_version(void) { return 1; }
+
+int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
+{
+    if (!out)
+        return fail(IVFHNSW_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(IVFHNSW_ERR_HIP, "no HIP device available (%s); there is no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev)
+        return fail(IVFHNSW_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(IVFHNSW_ERR_HIP, "device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+    ivfhnsw_gpu *h = new ivfhnsw_gpu();
+    h->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete h;
+        return fail(IVFHNSW_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+    }
+    h->own_stream = true;
+    *out = h;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
+{
+    if (!h)
+        return IVFHNSW_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &ev : h->pending) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (auto e : h->pool)
+        (void)hipEventDestroy(e);
+    DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors,
+                     &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+    for (auto *b : all)
+        b->release();
+    if (h->own_stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_set_stream(ivfhnsw_gpu *h, void *hip_stream)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream)
+        (void)hipStreamDestroy(h->stream);
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    h->own_stream = false;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_sync(ivfhnsw_gpu *h)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = check_desc(d, true)))
+        return rc;
+    h->has_ivf = false;
+    std::vector<uint32_t> loff;
+    uint64_t n_local = 0;
+    if ((rc = upload_tables(h, d, loff, n_local)))
+        return rc;
+    if ((rc = upload(h->codes, d->codes, n_local * d->code_size)))
+        return rc;
+    if ((rc = upload(h->ncodes, d->norm_codes, n_local)))
+        return rc;
+    if ((rc = upload(h->ids, d->ids, n_local * sizeof(uint32_t))))
+        return rc;
+    h->t.codes = h->codes.as<uint8_t>();
+    h->t.norm_codes = h->ncodes.as<uint8_t>();
+    h->t.ids = h->ids.as<uint32_t>();
+    h->n_local = n_local;
+    h->has_ivf = true;
+    h->has_group = false;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, uint64_t seed)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = check_desc(d, false)))
+        return rc;
+    if (d->shard_world != 1)
+        return fail(IVFHNSW_ERR_INVALID, "synthetic corpus: generate per shard with shard_world == 1 tables");
+    h->has_ivf = false;
+    std::vector<uint32_t> loff;
+    uint64_t n_local = 0;
+    if ((rc = upload_tables(h, d, loff, n_local)))
+        return rc;
+    if ((rc = h->codes.ensure(n_local * d->code_size)))
+        return rc;
+    if ((rc = h->ncodes.ensure(n_local)))
+        return rc;
+    if ((rc = h->ids.ensure(n_local * sizeof(uint32_t))))
+        return rc;
+    HIP_TRY(launch_fill_bytes(h->stream, h->codes.as<uint8_t>(), n_local * d->code_size, seed));
+    HIP_TRY(launch_fill_bytes(h->stream, h->ncodes.as<uint8_t>(), n_local, seed ^ 0x6e6f726d6e6f726dull));
+    HIP_TRY(launch_fill_iota(h->stream, h->ids.as<uint32_t>(), n_local, 0));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->t.codes = h->codes.as<uint8_t>();
+    h->t.norm_codes = h->ncodes.as<uint8_t>();
+    h->t.ids = h->ids.as<uint32_t>();
+    h->n_local = n_local;
+    h->has_ivf = true;
+    h->has_group = false;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alphas, const uint32_t *nn_centroid_idxs,
+                                const uint32_t *subgroup_sizes, const float *inter_centroid_dists)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "upload_grouping before upload_ivf");
+    if (nsubc == 0 || nsubc > 4096 || !alphas || !nn_centroid_idxs || !subgroup_sizes || !inter_centroid_dists)
+        return fail(IVFHNSW_ERR_INVALID, "bad grouping tables (nsubc %zu)", nsubc);
+    const size_t nc = h->t.nc;
+    // every group's sub-group sizes must add up to the list size, and neighbours must be valid ids
+    {
+        std::vector<uint64_t> goff(nc + 1);
+        HIP_TRY(hipMemcpy(goff.data(), h->goff.p, (nc + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < nc; c++) {
+            uint64_t s = 0;
+            for (size_t j = 0; j < nsubc; j++) {
+                s += subgroup_sizes[c * nsubc + j];
+                if (subgroup_sizes[c * nsubc + j] && nn_centroid_idxs[c * nsubc + j] >= nc)
+                    return fail(IVFHNSW_ERR_INVALID, "nn_centroid_idxs[%zu][%zu] out of range", c, j);
+            }
+            if (s != goff[c + 1] - goff[c])
+                return fail(IVFHNSW_ERR_INVALID, "subgroup sizes of list %zu sum to %llu, list holds %llu", c,
+                            (unsigned long long)s, (unsigned long long)(goff[c + 1] - goff[c]));
+        }
+    }
+    if ((rc = upload(h->g_alpha, alphas, nc * sizeof(float))))
+        return rc;
+    if ((rc = upload(h->g_nn, nn_centroid_idxs, nc * nsubc * sizeof(uint32_t))))
+        return rc;
+    if ((rc = upload(h->g_sizes, subgroup_sizes, nc * nsubc * sizeof(uint32_t))))
+        return rc;
+    if ((rc = upload(h->g_inter, inter_centroid_dists, nc * nsubc * sizeof(float))))
+        return rc;
+    h->g.nsubc = (int)nsubc;
+    h->g.alphas = h->g_alpha.as<float>();
+    h->g.nn_idx = h->g_nn.as<uint32_t>();
+    h->g.sub_sizes = h->g_sizes.as<uint32_t>();
+    h->g.inter_dists = h->g_inter.as<float>();
+    h->has_group = true;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
+                                 const uint8_t *link_counts, const uint32_t *links, const float *vectors)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (n == 0 || d == 0 || maxM == 0 || maxM > 255 || n >= 0xffffffffull || enterpoint >= n || !link_counts ||
+        !links || !vectors)
+        return fail(IVFHNSW_ERR_INVALID, "bad quantizer arrays (n %zu, d %zu, maxM %zu)", n, d, maxM);
+    if (d % 16)
+        return fail(IVFHNSW_ERR_INVALID, "d %zu: the reference distance ignores dims beyond a multiple of 16 "
+                                         "(hnswalg.cpp:330); only multiples of 16 are supported here", d);
+    for (size_t i = 0; i < n; i++) {
+        if (link_counts[i] > maxM)
+            return fail(IVFHNSW_ERR_INVALID, "node %zu has %u links > maxM %zu", i, link_counts[i], maxM);
+        for (size_t j = 0; j < link_counts[i]; j++)
+            if (links[i * maxM + j] >= n)
+                return fail(IVFHNSW_ERR_INVALID, "node %zu link %zu out of range", i, j);
+    }
+    if ((rc = upload(h->q_counts, link_counts, n)))
+        return rc;
+    if ((rc = upload(h->q_links, links, n * maxM * sizeof(uint32_t))))
+        return rc;
+    if ((rc = upload(h->q_vectors, vectors, n * d * sizeof(float))))
+        return rc;
+    h->gr.n = (uint32_t)n;
+    h->gr.d = (int)d;
+    h->gr.maxM = (int)maxM;
+    h->gr.enterpoint = enterpoint;
+    h->gr.counts = h->q_counts.as<uint8_t>();
+    h->gr.links = h->q_links.as<uint32_t>();
+    h->gr.vectors = h->q_vectors.as<float>();
+    h->has_graph = true;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, size_t nprobe, size_t efSearch,
+                           uint32_t *d_coarse_ids, float *d_coarse_dists)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "coarse search needs upload_quantizer");
+    if (nprobe == 0 || efSearch < nprobe)
+        return fail(IVFHNSW_ERR_INVALID, "efSearch %zu < nprobe %zu (precondition of IndexIVF_HNSW.cpp:249-258)",
+                    efSearch, nprobe);
+    if (efSearch > 1024)
+        return fail(IVFHNSW_ERR_INVALID, "efSearch %zu > 1024 unsupported on the device", efSearch);
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (nq > 0x7fffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "nq too large");
+    // one visited bitmap per resident wavefront slot
+    const size_t words = ((size_t)h->gr.n + 31) / 32;
+    const int nslots = (int)std::min<size_t>(nq, 256 * 8);
+    if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
+        return rc;
+    StageScope sc(h, IVFHNSW_STAGE_COARSE);
+    HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
+                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
+                           const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
+                           int64_t *d_labels, int64_t *d_out_keys)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "search before upload_ivf");
+    if (!p || p->nprobe == 0 || k == 0)
+        return fail(IVFHNSW_ERR_INVALID, "nprobe and k must be positive");
+    if ((d_coarse_ids == nullptr) != (d_coarse_dists == nullptr))
+        return fail(IVFHNSW_ERR_INVALID, "coarse_ids and coarse_dists must both be given or both be NULL");
+    if (nq > 0 && (!d_queries || !d_distances || !d_labels))
+        return fail(IVFHNSW_ERR_INVALID, "null query/result buffer");
+    if (k > 1024)
+        return fail(IVFHNSW_ERR_INVALID, "k %zu > 1024 unsupported", k);
+    if (nq > 0x7fffffffull / (k > p->nprobe ? k : p->nprobe))
+        return fail(IVFHNSW_ERR_INVALID, "nq too large");
+    if (h->has_group && !h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "Grouping search needs upload_quantizer (sub-centroid distances)");
+    if (h->has_graph && (h->gr.d != h->t.d || h->gr.n != h->t.nc))
+        return fail(IVFHNSW_ERR_STATE, "quantizer (%u x %d) does not match the index (%u x %d)", h->gr.n, h->gr.d,
+                    h->t.nc, h->t.d);
+    h->last_nq = 0;
+    if (nq == 0)
+        return IVFHNSW_OK;
+
+    const int d = h->t.d, M = h->t.M, nprobe = (int)p->nprobe;
+    const int max_seg = h->has_group ? nprobe * h->g.nsubc : nprobe;
+    if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
+        return rc;
+    if ((rc = h->w_segs.ensure(nq * (size_t)max_seg * sizeof(Seg))))
+        return rc;
+    if ((rc = h->w_lpos.ensure(nq * (size_t)max_seg * sizeof(uint32_t))))
+        return rc;
+    if ((rc = h->w_hdr.ensure(nq * sizeof(PlanHdr))))
+        return rc;
+    if ((rc = h->w_keys.ensure(nq * k * sizeof(uint64_t))))
+        return rc;
+    if ((rc = h->w_totals.ensure(2 * sizeof(unsigned long long))))
+        return rc;
+
+    // 1. rotate (IndexIVF_HNSW.cpp:240)
+    const float *xq = d_queries;
+    if (h->t.opq_At) {
+        if ((rc = h->w_xq.ensure(nq * (size_t)d * sizeof(float))))
+            return rc;
+        StageScope sc(h, IVFHNSW_STAGE_OPQ);
+        HIP_TRY(launch_opq(h->stream, h->t.opq_At, d_queries, h->w_xq.as<float>(), (int)nq, d));
+        xq = h->w_xq.as<float>();
+    }
+    // 2. coarse (IndexIVF_HNSW.cpp:248-259)
+    const uint32_t *cid = d_coarse_ids;
+    const float *cd = d_coarse_dists;
+    if (!cid) {
+        if ((rc = h->w_cid.ensure(nq * (size_t)nprobe * sizeof(uint32_t))))
+            return rc;
+        if ((rc = h->w_cd.ensure(nq * (size_t)nprobe * sizeof(float))))
+            return rc;
+        if ((rc = ivfhnsw_gpu_coarse_dev(h, nq, xq, p->nprobe, p->efSearch, h->w_cid.as<uint32_t>(),
+                                         h->w_cd.as<float>())))
+            return rc;
+        cid = h->w_cid.as<uint32_t>();
+        cd = h->w_cd.as<float>();
+    }
+    // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
+    {
+        StageScope sc(h, IVFHNSW_STAGE_PLAN);
+        if (h->has_group) {
+            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * sizeof(float))))
+                return rc;
+            HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
+                                         p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                                         h->w_hdr.as<PlanHdr>(), max_seg, h->w_keys.as<uint64_t>(), (int)k,
+                                         h->w_qsd.as<float>()));
+        } else {
+            HIP_TRY(launch_plan_ivf(h->stream, h->t, cid, cd, (int)nq, nprobe, p->max_codes, h->w_segs.as<Seg>(),
+                                    h->w_lpos.as<uint32_t>(), h->w_hdr.as<PlanHdr>(), max_seg,
+                                    h->w_keys.as<uint64_t>(), (int)k));
+        }
+    }
+    // 4. table (IndexIVF_HNSW.cpp:262)
+    {
+        StageScope sc(h, IVFHNSW_STAGE_LUT);
+        HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq));
+    }
+    // 5. scan (IndexIVF_HNSW.cpp:282-289)
+    {
+        // small batches: split each query over several workgroups so the chip still fills
+        int nsplit = 1;
+        if (k == 1 && nq < 1024)
+            nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
+        StageScope sc(h, IVFHNSW_STAGE_SCAN);
+        HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                            h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>()));
+    }
+    // 6. select
+    {
+        StageScope sc(h, IVFHNSW_STAGE_SELECT);
+        HIP_TRY(launch_select(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
+                              h->w_keys.as<uint64_t>(), (int)nq, (int)k, d_distances, d_labels, d_out_keys));
+    }
+    h->last_nq = (int)nq;
+    h->last_max_seg = max_seg;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *d_keys, float *d_distances,
+                                 int64_t *d_labels)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf || h->last_nq == 0 || (size_t)h->last_nq != nq)
+        return fail(IVFHNSW_ERR_STATE, "resolve_keys needs the plan of a preceding search_dev with the same nq");
+    StageScope sc(h, IVFHNSW_STAGE_SELECT);
+    HIP_TRY(launch_resolve(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), h->last_max_seg, d_keys,
+                           (int)nq, (int)k, d_distances, d_labels));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries, const uint32_t *coarse_ids,
+                       const float *coarse_dists, const ivfhnsw_search_params *p, float *distances, int64_t *labels)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "search before upload_ivf");
+    if (!p || p->nprobe == 0 || k == 0)
+        return fail(IVFHNSW_ERR_INVALID, "nprobe and k must be positive");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!queries || !distances || !labels)
+        return fail(IVFHNSW_ERR_INVALID, "null query/result buffer");
+    if ((coarse_ids == nullptr) != (coarse_dists == nullptr))
+        return fail(IVFHNSW_ERR_INVALID, "coarse_ids and coarse_dists must both be given or both be NULL");
+    const size_t d = h->t.d;
+    if ((rc = h->s_q.ensure(nq * d * sizeof(float))))
+        return rc;
+    if ((rc = h->s_dist.ensure(nq * k * sizeof(float))))
+        return rc;
+    if ((rc = h->s_lab.ensure(nq * k * sizeof(int64_t))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->s_q.p, queries, nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (coarse_ids) {
+        if ((rc = h->s_cid.ensure(nq * p->nprobe * sizeof(uint32_t))))
+            return rc;
+        if ((rc = h->s_cd.ensure(nq * p->nprobe * sizeof(float))))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(h->s_cid.p, coarse_ids, nq * p->nprobe * sizeof(uint32_t), hipMemcpyHostToDevice,
+                               h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_cd.p, coarse_dists, nq * p->nprobe * sizeof(float), hipMemcpyHostToDevice,
+                               h->stream));
+    }
+    rc = ivfhnsw_gpu_search_dev(h, nq, k, h->s_q.as<float>(), coarse_ids ? h->s_cid.as<uint32_t>() : nullptr,
+                                coarse_ids ? h->s_cd.as<float>() : nullptr, p, h->s_dist.as<float>(),
+                                h->s_lab.as<int64_t>(), nullptr);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(distances, h->s_dist.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(labels, h->s_lab.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    h->profiling = enabled != 0;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_get_stage_ms(ivfhnsw_gpu *h, int stage, double *ms_total, uint64_t *launches)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (stage < 0 || stage >= IVFHNSW_STAGE_COUNT)
+        return fail(IVFHNSW_ERR_INVALID, "bad stage %d", stage);
+    if ((rc = drain_events(h)))
+        return rc;
+    if (ms_total)
+        *ms_total = h->stage_ms[stage];
+    if (launches)
+        *launches = h->stage_n[stage];
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_reset_stage_ms(ivfhnsw_gpu *h)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = drain_events(h)))
+        return rc;
+    for (int i = 0; i < IVFHNSW_STAGE_COUNT; i++) {
+        h->stage_ms[i] = 0;
+        h->stage_n[i] = 0;
+    }
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nsegments)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    unsigned long long out[2] = {0, 0};
+    if (h->last_nq) {
+        HIP_TRY(launch_plan_totals(h->stream, h->w_hdr.as<PlanHdr>(), h->last_nq,
+                                   h->w_totals.as<unsigned long long>()));
+        HIP_TRY(hipMemcpyAsync(out, h->w_totals.p, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (ncodes)
+        *ncodes = out[0];
+    if (nsegments)
+        *nsegments = out[1];
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
+{
+    if (!h || !bytes)
+        return fail(IVFHNSW_ERR_INVALID, "null argument");
+    const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
+                           &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
+                           &h->q_vectors, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->s_dist, &h->s_lab};
+    uint64_t s = 0;
+    for (auto *b : all)
+        s += b->bytes;
+    *bytes = s;
+    return IVFHNSW_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,99 @@
+// Device-side data layout and kernel launchers of the gfx950 IVFADC search path.
+// Host code (capi.cpp) sees only the launch_* functions; kernels live in kernels_*.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ivfhnsw_gpu_impl {
+
+// One scored (sub)list of one query: the unit of the scan plan.
+// start  : index of the first code inside this shard's flat code array
+// len    : number of codes
+// vpos   : position of the first code in the query's global scan order (tie-break, and label lookup)
+// cterm  : the per-list constant of the distance: term1 (IndexIVF_HNSW.cpp:277) or term1+term2
+//          (IndexIVF_HNSW_Grouping.cpp:290,318)
+struct __attribute__((aligned(16))) Seg {
+    uint32_t start;
+    uint32_t len;
+    uint32_t vpos;
+    float cterm;
+};
+
+// Per-query plan header: nseg segments owned by this shard, `total` codes in them.
+struct __attribute__((aligned(8))) PlanHdr {
+    uint32_t nseg;
+    uint32_t total;
+};
+
+// Packed result key: (orderable(dist) << 32) | vpos.  Unsigned order of the key is the order of
+// (dist, scan position): strict '<' of IndexIVF_HNSW.cpp:285 == "smallest key wins".
+constexpr uint32_t kOrdFltMax = 0x7f7fffffu | 0x80000000u; // orderable(FLT_MAX)
+constexpr uint64_t kKeyInit = (uint64_t)kOrdFltMax << 32;  // accept iff key < kKeyInit
+constexpr uint64_t kSignFlip = 0x8000000000000000ull;      // keys leave the library as signed-orderable int64
+
+struct IvfTables {
+    int d, M, dsub;             // M == code_size
+    uint32_t nc;
+    const uint64_t *goff;       // [nc+1] global list offsets
+    const uint32_t *loff;       // [nc] first local code of list c (undefined when not owned)
+    const float *centroid_norms;
+    const float *pq_centroids;  // [M][256][dsub]
+    const float *norm_table;    // [256]
+    const float *opq_At;        // [d][d] TRANSPOSED: At[k*d+i] = A[i][k], or null
+    const uint8_t *codes;
+    const uint8_t *norm_codes;
+    const uint32_t *ids;
+    uint32_t shard_rank, shard_world;
+};
+
+struct GroupTables {
+    int nsubc;
+    const float *alphas;
+    const uint32_t *nn_idx;
+    const uint32_t *sub_sizes;
+    const float *inter_dists;
+};
+
+struct GraphTables {
+    uint32_t n;
+    int d, maxM;
+    uint32_t enterpoint;
+    const uint8_t *counts;
+    const uint32_t *links;   // [n][maxM]
+    const float *vectors;    // [n][d]
+};
+
+// y[q][i] = fmaf chain over k of A[i][k] * x[q][k]  (IndexIVF_HNSW.cpp:240)
+hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, int nq, int d);
+// tab[q][m][c] = <x_m, centroid[m][c]>  (IndexIVF_HNSW.cpp:262)
+hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq);
+// probe order + max_codes rule (IndexIVF_HNSW.cpp:267-292); also resets keys[nq*k] to kKeyInit
+hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids,
+                           const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs,
+                           uint32_t *lpos, PlanHdr *hdr, int max_seg, uint64_t *keys, int k);
+// Grouping: sub-centroid distances, pruning threshold, pass-2 plan (IndexIVF_HNSW_Grouping.cpp:222-353)
+hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
+                                const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
+                                int nprobe, uint64_t max_codes, int do_pruning, Seg *segs, uint32_t *lpos,
+                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *qsd_scratch);
+// the ADC loop (IndexIVF_HNSW.cpp:282-289 / IndexIVF_HNSW_Grouping.cpp:321-333)
+hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
+                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys);
+// keys -> (distance, label) through the plan; also emits signed-orderable keys when out_keys != null
+hipError_t launch_select(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                         const uint64_t *keys, int nq, int k, float *dist, int64_t *labels, int64_t *out_keys);
+// same, reading signed-orderable keys (after a cross-shard MIN)
+hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                          const int64_t *skeys, int nq, int k, float *dist, int64_t *labels);
+// HNSW walk, one wavefront per query (hnswalg.cpp:48-109,227-234)
+hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
+                         uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
+                         size_t visited_words_per_slot, int nslots);
+// synthetic corpus: uniform bytes from a counter hash; ids = running index
+hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
+hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
+// sum of PlanHdr.total / nseg over the batch into out[0], out[1]
+hipError_t launch_plan_totals(hipStream_t s, const PlanHdr *hdr, int nq, unsigned long long *out);
+
+} // namespace ivfhnsw_gpu_impl

@@ -1,0 +1,562 @@
+// gfx950 kernels of the IVFADC search path: OPQ rotation, PQ inner-product table, IVF scan plan,
+// ADC list scan, label resolution, synthetic corpus fill.
+//
+// Float contract (see DESIGN.md "Numerics"): every arithmetic step is an explicit round-to-nearest
+// intrinsic in the order the reference's source evaluates it; this file is built with
+// -ffp-contract=off so nothing else gets fused either.
+#include "ivfhnsw_kernels.h"
+
+#include <float.h>
+#include <algorithm>
+
+namespace ivfhnsw_gpu_impl {
+
+__device__ __forceinline__ uint32_t f32_orderable(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// ---------------------------------------------------------------------------------------------
+// OPQ rotation: y[q][i] = sum_k A[i][k] x[q][k] as a k-ordered fmaf chain (reference call site
+// IndexIVF_HNSW.cpp:240; faiss hands this to sgemm, whose order is unspecified).
+// One block per query, one thread per output dim; At is A transposed so reads coalesce.
+// ---------------------------------------------------------------------------------------------
+__global__ void opq_kernel(const float *__restrict__ At, const float *__restrict__ x, float *__restrict__ y, int d)
+{
+    extern __shared__ float s_x[];
+    const int q = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += blockDim.x)
+        s_x[i] = x[(size_t)q * d + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float acc = 0.0f;
+        for (int k = 0; k < d; k++)
+            acc = __fmaf_rn(At[(size_t)k * d + i], s_x[k], acc);
+        y[(size_t)q * d + i] = acc;
+    }
+}
+
+hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, int nq, int d)
+{
+    if (nq == 0)
+        return hipSuccess;
+    int threads = d < 256 ? ((d + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(opq_kernel, dim3(nq), dim3(threads), d * sizeof(float), s, At, x, y, d);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// PQ inner-product table (IndexIVF_HNSW.cpp:262): tab[q][m][c] = <x_m, centroid[m][c]>.
+// Order inside one product = faiss's SSE fvec_inner_product: 4 partial sums over blocks of 4,
+// zero-padded tail, then (s0+s1)+(s2+s3).
+// One block = LUT_QB queries x 256 code words: thread c keeps centroid[m][c][:] in registers and
+// reuses it for the block's queries, so the 128 KB codebook is read once per LUT_QB queries.
+// ---------------------------------------------------------------------------------------------
+constexpr int LUT_QB = 4;
+
+template <int DSUB>
+__device__ __forceinline__ float ip_sse_order(const float *x, const float *y, int dsub_rt)
+{
+    const int dsub = DSUB > 0 ? DSUB : dsub_rt;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= dsub; i += 4) {
+        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
+        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
+        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
+        s3 = __fadd_rn(s3, __fmul_rn(x[i + 3], y[i + 3]));
+    }
+    if (i < dsub)
+        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
+    if (i + 1 < dsub)
+        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
+    if (i + 2 < dsub)
+        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
+    return __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
+}
+
+template <int DSUB>
+__global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, const float *__restrict__ cb,
+                                                  float *__restrict__ luts, int nq, int d, int M, int dsub_rt)
+{
+    extern __shared__ float s_q[]; // [LUT_QB][d]
+    const int dsub = DSUB > 0 ? DSUB : dsub_rt;
+    const int q0 = blockIdx.x * LUT_QB;
+    const int nqb = min(LUT_QB, nq - q0);
+    for (int i = threadIdx.x; i < nqb * d; i += 256)
+        s_q[i] = xq[(size_t)q0 * d + i];
+    __syncthreads();
+    const int c = threadIdx.x;
+    constexpr int RMAX = DSUB > 0 ? DSUB : 64;
+    float row[RMAX];
+    for (int m = 0; m < M; m++) {
+        const float *src = cb + ((size_t)m * 256 + c) * dsub;
+        if constexpr (DSUB > 0 && DSUB % 4 == 0) {
+#pragma unroll
+            for (int i = 0; i < DSUB; i += 4) {
+                float4 v = *reinterpret_cast<const float4 *>(src + i);
+                row[i] = v.x, row[i + 1] = v.y, row[i + 2] = v.z, row[i + 3] = v.w;
+            }
+        } else {
+            for (int i = 0; i < dsub; i++)
+                row[i] = src[i];
+        }
+        for (int qi = 0; qi < nqb; qi++) {
+            float r = ip_sse_order<DSUB>(s_q + qi * d + m * dsub, row, dsub);
+            luts[((size_t)(q0 + qi) * M + m) * 256 + c] = r;
+        }
+    }
+}
+
+hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq)
+{
+    if (nq == 0)
+        return hipSuccess;
+    dim3 grid((nq + LUT_QB - 1) / LUT_QB), block(256);
+    size_t shm = (size_t)LUT_QB * t.d * sizeof(float);
+    switch (t.dsub) {
+    case 4: hipLaunchKernelGGL(lut_kernel<4>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    case 8: hipLaunchKernelGGL(lut_kernel<8>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    case 12: hipLaunchKernelGGL(lut_kernel<12>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    case 16: hipLaunchKernelGGL(lut_kernel<16>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    default:
+        if (t.dsub > 64)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(lut_kernel<0>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// IVF scan plan (IndexIVF_HNSW.cpp:267-292): probes nearest first, empty lists skipped, stop after
+// the list that makes ncode >= max_codes.  Depends only on coarse results and list sizes, never on
+// codes, so it is computed up front and the scan itself is order-free.  One thread per query.
+// ---------------------------------------------------------------------------------------------
+__global__ void plan_ivf_kernel(IvfTables t, const uint32_t *__restrict__ cid, const float *__restrict__ cd, int nq,
+                                int nprobe, unsigned long long max_codes, Seg *__restrict__ segs,
+                                uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr, int max_seg,
+                                unsigned long long *__restrict__ keys, int k)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq)
+        return;
+    for (int j = 0; j < k; j++)
+        keys[(size_t)q * k + j] = kKeyInit;
+    unsigned long long ncode = 0;
+    uint32_t nl = 0, ns = 0;
+    Seg *sq = segs + (size_t)q * max_seg;
+    uint32_t *lq = lpos + (size_t)q * max_seg;
+    for (int i = 0; i < nprobe; i++) {
+        const uint32_t c = cid[(size_t)q * nprobe + i];
+        if (c >= t.nc)
+            continue; // padding slot (fewer than nprobe coarse results)
+        const unsigned long long n = t.goff[c + 1] - t.goff[c];
+        if (n == 0)
+            continue;
+        if (c % t.shard_world == t.shard_rank) {
+            Seg sg;
+            sg.start = t.loff[c];
+            sg.len = (uint32_t)n;
+            sg.vpos = (uint32_t)ncode;
+            sg.cterm = __fsub_rn(cd[(size_t)q * nprobe + i], t.centroid_norms[c]);
+            sq[ns] = sg;
+            lq[ns] = nl;
+            nl += (uint32_t)n;
+            ns++;
+        }
+        ncode += n;
+        if (ncode >= max_codes)
+            break;
+    }
+    PlanHdr h;
+    h.nseg = ns;
+    h.total = nl;
+    hdr[q] = h;
+}
+
+hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids, const float *coarse_dists,
+                           int nq, int nprobe, uint64_t max_codes, Seg *segs, uint32_t *lpos, PlanHdr *hdr,
+                           int max_seg, uint64_t *keys, int k)
+{
+    if (nq == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(plan_ivf_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, t, coarse_ids, coarse_dists, nq,
+                       nprobe, (unsigned long long)max_codes, segs, lpos, hdr, max_seg,
+                       reinterpret_cast<unsigned long long *>(keys), k);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// ADC list scan, k = 1 (IndexIVF_HNSW.cpp:282-289, IndexIVF_HNSW_Grouping.cpp:321-333).
+//
+// One 256-thread workgroup per (query, split).  The query's 256-entry-per-byte table (CS KB as
+// f32) and the 256-entry norm table are staged in LDS; the plan's segments are flattened into one
+// virtual array of `total` codes and lane t of iteration it scores position it*256*U + u*256 + t,
+// so consecutive lanes read consecutive CS-byte codes (one global_load_dwordx4 per lane for CS=16:
+// 1 KiB per wave instruction) and a wave only diverges in its base address at a list boundary.
+// Per code: CS LDS gathers summed in m order, dist = (cterm + norm) - 2*sum, packed into a
+// (distance, scan position) key; the wave/block minimum is the reference's strict-'<' first-wins top-1.
+// Bound: HBM read of CS+1 bytes per code; the CS LDS gathers per code run at about the same rate
+// (random bank conflicts), see DESIGN.md.
+// ---------------------------------------------------------------------------------------------
+template <int CS>
+__device__ __forceinline__ void load_code_words(const uint8_t *__restrict__ codes, uint32_t gi, uint32_t (&w)[CS / 4])
+{
+    const uint8_t *p = codes + (size_t)gi * CS;
+    if constexpr (CS % 16 == 0) {
+#pragma unroll
+        for (int i = 0; i < CS / 16; i++) {
+            uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+            w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+        }
+    } else if constexpr (CS % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < CS / 8; i++) {
+            uint2 v = reinterpret_cast<const uint2 *>(p)[i];
+            w[2 * i] = v.x, w[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CS / 4; i++)
+            w[i] = reinterpret_cast<const uint32_t *>(p)[i];
+    }
+}
+
+// IndexIVF_HNSW.cpp:802-814: result starts at 0 and adds table entries for m = 0..CS-1 in order.
+template <int CS>
+__device__ __forceinline__ float adc_sum(const float *s_lut, const uint32_t (&w)[CS / 4])
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < CS; m++) {
+        const uint32_t b = (w[m >> 2] >> ((m & 3) * 8)) & 0xffu;
+        sum = __fadd_rn(sum, s_lut[m * 256 + b]);
+    }
+    return sum;
+}
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint64_t o = __shfl_xor((unsigned long long)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int CS, int SEGCAP, int U>
+__global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict__ codes,
+                                                      const uint8_t *__restrict__ norm_codes,
+                                                      const float *__restrict__ luts,
+                                                      const float *__restrict__ norm_table,
+                                                      const Seg *__restrict__ segs, const uint32_t *__restrict__ lpos,
+                                                      const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
+                                                      unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
+    __shared__ float s_norm[256];
+    __shared__ __attribute__((aligned(16))) Seg s_seg[SEGCAP];
+    __shared__ uint32_t s_lpos[SEGCAP + 1];
+    __shared__ unsigned long long s_red[4];
+
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / nsplit;
+    const int split = blockIdx.x - q * nsplit;
+    const PlanHdr h = hdr[q];
+    if (h.total == 0)
+        return;
+    // this split's slice of the virtual code array, in multiples of the block width
+    uint32_t per = (h.total + nsplit - 1) / nsplit;
+    per = (per + 255u) & ~255u;
+    const uint32_t lo = min((uint32_t)split * per, h.total);
+    const uint32_t hi = min(lo + per, h.total);
+    if (lo >= hi)
+        return;
+
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
+        float4 *dst = reinterpret_cast<float4 *>(s_lut);
+#pragma unroll
+        for (int i = 0; i < CS * 64 / 256; i++)
+            dst[i * 256 + tid] = src[i * 256 + tid];
+        s_norm[tid] = norm_table[tid];
+    }
+
+    const Seg *sq = segs + (size_t)q * max_seg;
+    const uint32_t *lq = lpos + (size_t)q * max_seg;
+    unsigned long long best = kKeyInit;
+
+    for (uint32_t cs = 0; cs < h.nseg; cs += SEGCAP) {
+        const uint32_t cn = min((uint32_t)SEGCAP, h.nseg - cs);
+        __syncthreads(); // previous chunk fully consumed (and LUT staged, first time)
+        for (uint32_t i = tid; i < cn; i += 256) {
+            s_seg[i] = sq[cs + i];
+            s_lpos[i] = lq[cs + i];
+        }
+        const uint32_t ch = (cs + cn == h.nseg) ? h.total : lq[cs + cn];
+        if (tid == 0)
+            s_lpos[cn] = ch;
+        __syncthreads();
+        const uint32_t cl = s_lpos[0];
+        const uint32_t b0 = max(cl, lo), b1 = min(ch, hi);
+        uint32_t s = 0;
+        for (uint32_t base = b0; base < b1; base += 256 * U) {
+            uint32_t w[U][CS / 4];
+            uint32_t nb[U], vp[U];
+            float ct[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t p = base + u * 256 + tid;
+                ok[u] = p < b1;
+                if (ok[u]) {
+                    if constexpr (SEGCAP <= 64) {
+                        while (p >= s_lpos[s + 1])
+                            s++;
+                    } else {
+                        // first s with s_lpos[s+1] > p, searched in (s, cn)
+                        uint32_t a = s, b = cn - 1;
+                        while (a < b) {
+                            const uint32_t mid = (a + b) >> 1;
+                            if (s_lpos[mid + 1] > p)
+                                b = mid;
+                            else
+                                a = mid + 1;
+                        }
+                        s = a;
+                    }
+                    const Seg sg = s_seg[s];
+                    const uint32_t off = p - s_lpos[s];
+                    const uint32_t gi = sg.start + off;
+                    load_code_words<CS>(codes, gi, w[u]);
+                    nb[u] = norm_codes[gi];
+                    vp[u] = sg.vpos + off;
+                    ct[u] = sg.cterm;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (ok[u]) {
+                    const float sum = adc_sum<CS>(s_lut, w[u]);
+                    const float tt = __fadd_rn(ct[u], s_norm[nb[u]]);
+                    const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
+                    if (dist < FLT_MAX) { // also rejects NaN, as 'dist < distances[0]' does
+                        const unsigned long long key =
+                            ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | vp[u];
+                        best = key < best ? key : best;
+                    }
+                }
+            }
+        }
+    }
+
+    best = wave_min_u64(best);
+    if ((tid & 63) == 0)
+        s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = s_red[0];
+        b = s_red[1] < b ? s_red[1] : b;
+        b = s_red[2] < b ? s_red[2] : b;
+        b = s_red[3] < b ? s_red[3] : b;
+        if (nsplit == 1)
+            keys[q] = b;
+        else if (b < kKeyInit)
+            atomicMin(&keys[q], b);
+    }
+}
+
+template <int CS>
+static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
+                                 const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
+                                 uint64_t *keys)
+{
+    dim3 grid((unsigned)nq * nsplit), block(256);
+    auto *k64 = reinterpret_cast<unsigned long long *>(keys);
+    if (max_seg <= 64)
+        hipLaunchKernelGGL((scan_k1_kernel<CS, 64, 4>), grid, block, 0, s, t.codes, t.norm_codes, luts, t.norm_table,
+                           segs, lpos, hdr, max_seg, nsplit, k64);
+    else
+        hipLaunchKernelGGL((scan_k1_kernel<CS, 1024, 4>), grid, block, 0, s, t.codes, t.norm_codes, luts,
+                           t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
+                            const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int k, uint64_t *keys);
+
+hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
+                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys)
+{
+    if (nq == 0)
+        return hipSuccess;
+    if (k != 1)
+        return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys);
+    switch (t.M) {
+    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
+    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
+    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
+    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// keys -> (distance, label): the winner's scan position is looked up in the plan (segments are in
+// scan order, so vpos ascends) and the label read from this shard's id array.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resolve_key(unsigned long long key, const IvfTables &t, const Seg *sq, uint32_t nseg,
+                                            float *dist, long long *label)
+{
+    const uint32_t hiw = (uint32_t)(key >> 32), vpos = (uint32_t)key;
+    if (key >= kKeyInit) {
+        *dist = FLT_MAX;
+        *label = -1;
+        return;
+    }
+    *dist = orderable_f32(hiw);
+    *label = -1;
+    if (nseg == 0)
+        return;
+    uint32_t a = 0, b = nseg - 1; // last segment with seg.vpos <= vpos
+    while (a < b) {
+        const uint32_t mid = (a + b + 1) >> 1;
+        if (sq[mid].vpos <= vpos)
+            a = mid;
+        else
+            b = mid - 1;
+    }
+    const Seg sg = sq[a];
+    if (vpos >= sg.vpos && vpos - sg.vpos < sg.len)
+        *label = (long long)t.ids[sg.start + (vpos - sg.vpos)];
+}
+
+__global__ void select_kernel(IvfTables t, const Seg *__restrict__ segs, const PlanHdr *__restrict__ hdr, int max_seg,
+                              const unsigned long long *__restrict__ keys, int nq, int k, float *__restrict__ dist,
+                              long long *__restrict__ labels, long long *__restrict__ out_keys, int keys_signed)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nq * k)
+        return;
+    const int q = (int)(i / k);
+    unsigned long long key = keys[i];
+    if (keys_signed)
+        key ^= kSignFlip;
+    float dv;
+    long long lb;
+    resolve_key(key, t, segs + (size_t)q * max_seg, hdr[q].nseg, &dv, &lb);
+    dist[i] = dv;
+    labels[i] = lb;
+    if (out_keys)
+        out_keys[i] = (long long)(key ^ kSignFlip);
+}
+
+hipError_t launch_select(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                         const uint64_t *keys, int nq, int k, float *dist, int64_t *labels, int64_t *out_keys)
+{
+    const size_t n = (size_t)nq * k;
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, segs, hdr, max_seg,
+                       reinterpret_cast<const unsigned long long *>(keys), nq, k, dist,
+                       reinterpret_cast<long long *>(labels), reinterpret_cast<long long *>(out_keys), 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                          const int64_t *skeys, int nq, int k, float *dist, int64_t *labels)
+{
+    const size_t n = (size_t)nq * k;
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t, segs, hdr, max_seg,
+                       reinterpret_cast<const unsigned long long *>(skeys), nq, k, dist,
+                       reinterpret_cast<long long *>(labels), (long long *)nullptr, 1);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic corpus: byte b of stream(seed) = byte (b % 8) of
+// mix64(seed + (b / 8 + 1) * 0x9E3779B97F4A7C15); reproducible on the host with numpy.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ void fill_bytes_kernel(uint8_t *__restrict__ dst, size_t nwords, size_t nbytes, unsigned long long seed)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+        const unsigned long long v = mix64(seed + (w + 1) * 0x9E3779B97F4A7C15ull);
+        if ((w + 1) * 8 <= nbytes) {
+            reinterpret_cast<unsigned long long *>(dst)[w] = v;
+        } else {
+            for (size_t b = w * 8; b < nbytes; b++)
+                dst[b] = (uint8_t)(v >> (8 * (b & 7)));
+        }
+    }
+}
+
+hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed)
+{
+    if (nbytes == 0)
+        return hipSuccess;
+    const size_t nwords = (nbytes + 7) / 8;
+    const unsigned grid = (unsigned)std::min<size_t>((nwords + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3(grid), dim3(256), 0, s, dst, nwords, nbytes, (unsigned long long)seed);
+    return hipGetLastError();
+}
+
+__global__ void fill_iota_kernel(uint32_t *__restrict__ dst, size_t n, uint32_t first)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = first + (uint32_t)i;
+}
+
+hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first)
+{
+    if (n == 0)
+        return hipSuccess;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(fill_iota_kernel, dim3(grid), dim3(256), 0, s, dst, n, first);
+    return hipGetLastError();
+}
+
+__global__ void plan_totals_kernel(const PlanHdr *__restrict__ hdr, int nq, unsigned long long *out)
+{
+    unsigned long long tc = 0, ts = 0;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        tc += hdr[q].total;
+        ts += hdr[q].nseg;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        tc += __shfl_xor(tc, off, 64);
+        ts += __shfl_xor(ts, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], tc);
+        atomicAdd(&out[1], ts);
+    }
+}
+
+hipError_t launch_plan_totals(hipStream_t s, const PlanHdr *hdr, int nq, unsigned long long *out)
+{
+    hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), s);
+    if (e != hipSuccess || nq == 0)
+        return e;
+    hipLaunchKernelGGL(plan_totals_kernel, dim3(std::min((nq + 255) / 256, 256)), dim3(256), 0, s, hdr, nq, out);
+    return hipGetLastError();
+}
+
+} // namespace ivfhnsw_gpu_impl

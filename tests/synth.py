@@ -1,0 +1,216 @@
+"""Seeded synthetic corpora for the parity tests and bench.py.
+
+Two kinds:
+  * make_corpus(): a small, *real* index built the way the reference builds one (IndexIVF_HNSW.cpp:75-138,
+    IndexIVF_HNSW_Grouping.cpp:43-157): base = centroid + noise -> residual -> (OPQ) -> PQ encode ->
+    reconstruct -> quantised norm; HNSW graph by the oracle's reference-identical serial construction.
+  * make_throughput_corpus(): SIFT1B-shaped tables with list sizes only; codes are the counter-hash byte
+    stream the device generates itself (ivfhnsw_gpu_upload_ivf_synthetic), reproduced here in numpy.
+
+No reference data, no downloads: everything is generated from the seed.
+"""
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from oracle import orc  # noqa: E402
+
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+NORM_SEED_XOR = np.uint64(0x6e6f726d6e6f726d)
+
+
+def _mix64(z):
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_bytes(seed, first_byte, nbytes):
+    """Bytes [first_byte, first_byte+nbytes) of the device's synthetic stream (kernels_search.hip fill_bytes)."""
+    if nbytes == 0:
+        return np.zeros(0, np.uint8)
+    w0 = first_byte // 8
+    w1 = (first_byte + nbytes + 7) // 8
+    with np.errstate(over="ignore"):
+        w = np.arange(w0, w1, dtype=np.uint64)
+        v = _mix64(np.uint64(seed) + (w + np.uint64(1)) * GOLDEN)
+    b = v.view(np.uint8)  # little endian: byte i of word = (v >> 8i) & 0xff
+    s = first_byte - w0 * 8
+    return b[s:s + nbytes].copy()
+
+
+def sift_like(rng, n, d):
+    """Non-negative, byte-ranged vectors (SIFT descriptors are uint8 histograms)."""
+    x = rng.normal(30.0, 35.0, size=(n, d))
+    return np.clip(np.rint(x), 0, 255).astype(np.float32)
+
+
+def random_rotation(rng, d):
+    q, r = np.linalg.qr(rng.normal(size=(d, d)))
+    q = q * np.sign(np.diag(r))
+    return np.ascontiguousarray(q.astype(np.float32))
+
+
+def _pq_encode(res, cb):
+    """Nearest code word per sub-space.  res [n,d], cb [M,256,dsub] -> codes [n,M] uint8."""
+    n, d = res.shape
+    M, _, dsub = cb.shape
+    codes = np.empty((n, M), np.uint8)
+    for m in range(M):
+        sub = res[:, m * dsub:(m + 1) * dsub]
+        c = cb[m]
+        dist = (sub * sub).sum(1, keepdims=True) - 2.0 * sub @ c.T + (c * c).sum(1)[None, :]
+        codes[:, m] = dist.argmin(1).astype(np.uint8)
+    return codes
+
+
+def _pq_decode(codes, cb):
+    n, M = codes.shape
+    dsub = cb.shape[2]
+    out = np.empty((n, M * dsub), np.float32)
+    for m in range(M):
+        out[:, m * dsub:(m + 1) * dsub] = cb[m][codes[:, m]]
+    return out
+
+
+def make_corpus(seed=1234, nc=256, d=128, M=16, n_base=20000, opq=False, nsubc=0, hnsw_M=16, efConstruction=200,
+                empty_frac=0.05, noise=12.0, nq=64, query_noise=10.0):
+    """Small real index.  Returns a dict of numpy arrays + the oracle graph handle."""
+    rng = np.random.default_rng(seed)
+    dsub = d // M
+    centroids = sift_like(rng, nc, d)
+    graph = orc.Hnsw.build(centroids, M=hnsw_M, efConstruction=efConstruction)
+
+    # list membership: skewed sizes, a few empty lists (reference skips them, IndexIVF_HNSW.cpp:271)
+    w = rng.gamma(2.0, 1.0, size=nc)
+    w[rng.random(nc) < empty_frac] = 0.0
+    w /= w.sum()
+    assign = rng.choice(nc, size=n_base, p=w).astype(np.uint32)
+    base = centroids[assign] + rng.normal(0.0, noise, size=(n_base, d)).astype(np.float32)
+    base = base.astype(np.float32)
+    ids = np.arange(n_base, dtype=np.uint32)
+
+    A = random_rotation(rng, d) if opq else None
+
+    out = dict(seed=seed, d=d, nc=nc, code_size=M, centroids=centroids, opq_A=A, nsubc=nsubc)
+
+    if nsubc:
+        # IndexIVF_HNSW_Grouping.cpp:47-63: the nsubc nearest other centroids, ascending distance
+        nn = np.zeros((nc, nsubc), np.uint32)
+        for c in range(nc):
+            found, _ = graph.search_knn(centroids[c], max(efConstruction, nsubc + 1), nsubc + 1)
+            assert len(found) == nsubc + 1, "graph too small for nsubc"
+            nn[c] = found[1:]
+        alphas = rng.uniform(0.0, 0.5, size=nc).astype(np.float32)
+        out.update(nn_centroid_idxs=nn, alphas=alphas)
+        # sub-centroid of (c, s) = c + alpha * (nn - c); each point goes to its nearest sub-centroid
+        subc_of = np.zeros(n_base, np.uint32)
+        sub_centroid = np.empty((n_base, d), np.float32)
+        for c in range(nc):
+            idx = np.nonzero(assign == c)[0]
+            if idx.size == 0:
+                continue
+            sc = centroids[c][None, :] + alphas[c] * (centroids[nn[c]] - centroids[c][None, :])
+            dist = ((base[idx][:, None, :] - sc[None, :, :]) ** 2).sum(2)
+            s = dist.argmin(1)
+            subc_of[idx] = s
+            sub_centroid[idx] = sc[s]
+        anchor = sub_centroid
+        order = np.lexsort((ids, subc_of, assign))  # list, then sub-group, then insertion order
+    else:
+        anchor = centroids[assign]
+        order = np.argsort(assign, kind="stable")
+
+    residual = (base - anchor).astype(np.float32)
+    if opq:
+        residual = (residual @ A.T).astype(np.float32)  # y = A x
+
+    # code books: 256 sampled residual sub-vectors per sub-space, jittered
+    cb = np.empty((M, 256, dsub), np.float32)
+    for m in range(M):
+        pick = rng.choice(n_base, size=256, replace=n_base < 256)
+        cb[m] = residual[pick, m * dsub:(m + 1) * dsub] + rng.normal(0, 0.5, size=(256, dsub)).astype(np.float32)
+    codes = _pq_encode(residual, cb)
+    dec = _pq_decode(codes, cb)
+    if opq:
+        dec = (dec @ A).astype(np.float32)  # x = A^T y
+    recon = (anchor + dec).astype(np.float32)
+    norms = (recon.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    # norm quantiser: 256 sorted quantiles; nearest entry
+    norm_table = np.quantile(norms, (np.arange(256) + 0.5) / 256).astype(np.float32)
+    norm_codes = np.abs(norms[:, None] - norm_table[None, :]).argmin(1).astype(np.uint8)
+
+    counts = np.bincount(assign, minlength=nc).astype(np.uint64)
+    offsets = np.zeros(nc + 1, np.uint64)
+    offsets[1:] = np.cumsum(counts)
+    out.update(offsets=offsets, ids=ids[order].copy(), codes=codes[order].copy(),
+               norm_codes=norm_codes[order].copy(), pq_centroids=cb, norm_table=norm_table,
+               centroid_norms=graph.centroid_norms(), base=base)
+
+    if nsubc:
+        sg = np.zeros((nc, nsubc), np.uint32)
+        np.add.at(sg, (assign, subc_of), 1)
+        out.update(subgroup_sizes=sg, inter_centroid_dists=graph.inter_centroid_dists(out["nn_centroid_idxs"]))
+
+    # the drivers rotate the graph's centroids after the index is complete (tests/test_ivfhnsw_sift1b.cpp:164-167)
+    if opq:
+        graph.rotate(A)
+    out["graph"] = graph
+
+    # queries near base points (so that the right list is usually probed), plus a few exact duplicates
+    qsrc = rng.choice(n_base, size=nq, replace=False)
+    queries = base[qsrc] + rng.normal(0.0, query_noise, size=(nq, d)).astype(np.float32)
+    queries[: max(1, nq // 16)] = base[qsrc[: max(1, nq // 16)]]
+    out["queries"] = np.ascontiguousarray(queries, np.float32)
+    out["query_src"] = qsrc
+    return out
+
+
+def oracle_index(c):
+    """orc.Index over a corpus dict."""
+    return orc.Index(c["d"], c["code_size"], c["graph"], c["pq_centroids"], c["norm_table"], c["offsets"], c["ids"],
+                     c["codes"], c["norm_codes"], c["centroid_norms"], opq_A=c["opq_A"], nsubc=c["nsubc"],
+                     alphas=c.get("alphas"), nn_centroid_idxs=c.get("nn_centroid_idxs"),
+                     subgroup_sizes=c.get("subgroup_sizes"), inter_centroid_dists=c.get("inter_centroid_dists"))
+
+
+def list_sizes(rng, nc, n_total, sigma=0.6, cap=65536):
+    """Log-normal list sizes summing to n_total, every list <= 65536 (IndexIVF_HNSW.cpp:17 scratch size)."""
+    w = rng.lognormal(0.0, sigma, size=nc)
+    sizes = np.floor(w / w.sum() * n_total).astype(np.int64)
+    sizes = np.minimum(sizes, cap)
+    short = n_total - int(sizes.sum())
+    if short > 0:
+        bump = rng.choice(nc, size=short, replace=True)
+        np.add.at(sizes, bump, 1)
+        sizes = np.minimum(sizes, cap)
+    return sizes.astype(np.uint64)
+
+
+def make_throughput_tables(seed, nc, d, M, n_total):
+    """Tables of a throughput corpus (no codes): centroids, code books, norm table, list offsets."""
+    rng = np.random.default_rng(seed)
+    dsub = d // M
+    centroids = sift_like(rng, nc, d)
+    sizes = list_sizes(rng, nc, n_total)
+    offsets = np.zeros(nc + 1, np.uint64)
+    offsets[1:] = np.cumsum(sizes)
+    cb = rng.normal(0.0, 12.0, size=(M, 256, dsub)).astype(np.float32)
+    # a reconstructed SIFT-like vector has squared norm around d * (30^2 + 35^2)
+    norm_table = np.sort(rng.normal(d * 2100.0, d * 300.0, size=256)).astype(np.float32)
+    return dict(seed=seed, d=d, nc=nc, code_size=M, centroids=centroids, offsets=offsets, pq_centroids=cb,
+                norm_table=norm_table, opq_A=None, nsubc=0)
+
+
+def synthetic_codes(seed, offsets, code_size):
+    """Host copy of what ivfhnsw_gpu_upload_ivf_synthetic generates on the device."""
+    n = int(offsets[-1])
+    codes = hash_bytes(seed, 0, n * code_size).reshape(n, code_size)
+    norm_codes = hash_bytes(int(np.uint64(seed) ^ NORM_SEED_XOR), 0, n)
+    ids = np.arange(n, dtype=np.uint32)
+    return ids, codes, norm_codes
