@@ -43,7 +43,9 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h);
 
 /* Optional: run on a caller-owned hipStream_t (passed as void*) instead of the handle's own stream. */
 int ivfhnsw_gpu_set_stream(ivfhnsw_gpu *h, void *hip_stream);
-/* Block until everything queued on the handle's stream has finished. */
+/* Block until everything queued on the handle's stream has finished.  Also reports (as
+ * IVFHNSW_ERR_STATE) a condition a kernel could not represent, e.g. more than 64 exact distance ties
+ * at the efSearch boundary of the HNSW walk; the host-pointer entry points check this themselves. */
 int ivfhnsw_gpu_sync(ivfhnsw_gpu *h);
 
 /* The inverted lists and the quantizer tables: the data members of IndexIVF_HNSW
@@ -135,6 +137,12 @@ int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int6
  * already be rotated when OPQ is on. */
 int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, size_t nprobe, size_t efSearch,
                            uint32_t *d_coarse_ids, float *d_coarse_dists);
+
+/* Host-pointer form of the coarse stage; with k = 1 this is IndexIVF_HNSW::assign
+ * (IndexIVF_HNSW.cpp:68-72) for n vectors.  The OPQ rotation is NOT applied (assign() takes vectors in
+ * the graph's space).  Slots beyond the number of nodes found hold 0xffffffff / 0. */
+int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k, size_t efSearch,
+                       uint32_t *ids, float *dists);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_last_error", "ivfhnsw_gpu_abi_version", "ivfhnsw_gpu_create", "ivfhnsw_gpu_destroy",
     "ivfhnsw_gpu_set_stream", "ivfhnsw_gpu_sync", "ivfhnsw_gpu_upload_ivf", "ivfhnsw_gpu_upload_ivf_synthetic",
     "ivfhnsw_gpu_upload_grouping", "ivfhnsw_gpu_upload_quantizer", "ivfhnsw_gpu_search", "ivfhnsw_gpu_search_dev",
-    "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_set_profiling",
+    "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes",
 )
@@ -75,6 +75,8 @@ def lib():
                                                    C.c_void_p]
         L.ivfhnsw_gpu_coarse_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                              C.c_void_p]
+        L.ivfhnsw_gpu_coarse.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                         C.c_void_p]
         L.ivfhnsw_gpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_get_stage_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
@@ -209,6 +211,15 @@ class GpuIndex:
     def coarse_dev(self, nq, d_queries, nprobe, efSearch, d_coarse_ids, d_coarse_dists):
         _check(lib().ivfhnsw_gpu_coarse_dev(self._h, nq, _devptr(d_queries), nprobe, efSearch,
                                             _devptr(d_coarse_ids), _devptr(d_coarse_dists)))
+
+    def coarse(self, queries, k, efSearch):
+        """Host arrays: the HNSW walk alone (k = 1: IndexIVF_HNSW::assign)."""
+        q = _np(queries, np.float32)
+        q = q.reshape(-1, q.shape[-1])
+        ids = np.empty((q.shape[0], k), np.uint32)
+        dist = np.empty((q.shape[0], k), np.float32)
+        _check(lib().ivfhnsw_gpu_coarse(self._h, q.shape[0], _ptr(q), k, efSearch, _ptr(ids), _ptr(dist)))
+        return ids, dist
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

@@ -88,7 +88,7 @@ struct ivfhnsw_gpu {
     bool has_graph = false;
 
     // per-batch workspace
-    DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited;
+    DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
 
@@ -168,6 +168,20 @@ int drain_events(ivfhnsw_gpu *h)
     }
     h->pending.clear();
     return IVFHNSW_OK;
+}
+
+// After a stream sync: did any kernel flag something it could not represent?
+int check_status(ivfhnsw_gpu *h)
+{
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, h->w_status.p, sizeof(st), hipMemcpyDeviceToHost));
+    if (!st)
+        return IVFHNSW_OK;
+    HIP_TRY(hipMemset(h->w_status.p, 0, sizeof(st)));
+    if (st & kStatusHnswTieOverflow)
+        return fail(IVFHNSW_ERR_STATE, "HNSW walk: more than 64 candidates tie exactly with the efSearch-th "
+                                       "distance; results of this batch are invalid");
+    return fail(IVFHNSW_ERR_STATE, "device status 0x%x", st);
 }
 
 int check_desc(const ivfhnsw_ivf_desc *d, bool need_lists)
@@ -285,6 +299,10 @@ int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
         return fail(IVFHNSW_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
     }
     h->own_stream = true;
+    if (h->w_status.ensure(sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, sizeof(uint32_t)) != hipSuccess) {
+        ivfhnsw_gpu_destroy(h);
+        return fail(IVFHNSW_ERR_HIP, "cannot allocate the device status word");
+    }
     *out = h;
     return IVFHNSW_OK;
 }
@@ -304,7 +322,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     if (h->own_stream)
@@ -332,7 +350,7 @@ int ivfhnsw_gpu_sync(ivfhnsw_gpu *h)
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return IVFHNSW_OK;
+    return check_status(h);
 }
 
 int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
@@ -499,8 +517,37 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         return rc;
     StageScope sc(h, IVFHNSW_STAGE_COARSE);
     HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots));
+                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>()));
     return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k, size_t efSearch, uint32_t *ids,
+                       float *dists)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "coarse search needs upload_quantizer");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!queries || !ids || !dists || k == 0)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer or k == 0");
+    const size_t d = h->gr.d;
+    if ((rc = h->s_q.ensure(nq * d * sizeof(float))))
+        return rc;
+    if ((rc = h->s_cid.ensure(nq * k * sizeof(uint32_t))))
+        return rc;
+    if ((rc = h->s_cd.ensure(nq * k * sizeof(float))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->s_q.p, queries, nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if ((rc = ivfhnsw_gpu_coarse_dev(h, nq, h->s_q.as<float>(), k, efSearch, h->s_cid.as<uint32_t>(),
+                                     h->s_cd.as<float>())))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(ids, h->s_cid.p, nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(dists, h->s_cd.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return check_status(h);
 }
 
 int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
@@ -667,7 +714,7 @@ int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries
     HIP_TRY(hipMemcpyAsync(distances, h->s_dist.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(labels, h->s_lab.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return IVFHNSW_OK;
+    return check_status(h);
 }
 
 int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled)
@@ -735,7 +782,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

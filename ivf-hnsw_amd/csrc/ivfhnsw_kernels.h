@@ -89,7 +89,9 @@ hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, co
 // HNSW walk, one wavefront per query (hnswalg.cpp:48-109,227-234)
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                         size_t visited_words_per_slot, int nslots);
+                         size_t visited_words_per_slot, int nslots, uint32_t *status);
+// bits of the device status word
+constexpr uint32_t kStatusHnswTieOverflow = 1u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
