@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the IVFADC search hot path on MI355X.
+
+One "step" = one pass of the whole hot path (rotate -> HNSW coarse walk -> PQ inner-product table ->
+scan plan -> ADC list scan -> top-1 select) over one batch of queries that is already resident in HBM.
+
+Workload (BASELINE.json configs[1]): synthetic 100M x 128-d, 2^17 centroids, PQ16, nprobe 32, 10 k-query
+batch, at the paper operating point (nprobe, max_codes, efSearch) = (32, 10000, 80)
+(reference examples/run_sift1b.sh:37-43).  SIFT1B-shaped synthetic data: see tests/synth.py.
+
+N > 1 (strong scaling): the inverted lists are sharded list-wise over the ranks
+(c % N == rank), every rank holds the replicated tables; the coarse walk is split over the ranks by
+query and all-gathered, every rank scans its shard for all queries, and the packed (distance, scan
+position) keys are MIN-all-reduced over RCCL, labels MAX-all-reduced.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak (spec)
+
+WORKLOADS = {
+    # name: (n_total, nc, d, M, nprobe, max_codes, efSearch, nq)
+    "synthetic-100M-pq16-nc131072-nprobe32": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
+    "synthetic-10M-pq16-nc16384-nprobe32": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
+    "synthetic-1M-pq8-nc4096-nprobe8": (1_000_000, 4096, 128, 8, 8, 10 ** 9, 40, 2000),
+}
+DEFAULT_WORKLOAD = "synthetic-100M-pq16-nc131072-nprobe32"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-coarse", action="store_true",
+                    help="feed the oracle's coarse stage instead of running the HNSW walk on the device (debug)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import synth
+
+    pkg = ge.load_pkg()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n_total, nc, d, M, nprobe, max_codes, ef, nq = WORKLOADS[args.workload]
+    t0 = time.time()
+    tb = synth.make_throughput_tables(args.seed, nc, d, M, n_total)
+    rng = np.random.default_rng(args.seed + 1)
+    # queries: SIFT-like points near centroids, so that walks end in populated regions
+    queries = (tb["centroids"][rng.choice(nc, nq)] + rng.normal(0, 12.0, size=(nq, d))).astype(np.float32)
+    counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
+    centroid_norms = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
+    if rank == 0:
+        log("[bench] tables + graph: %.1fs (avg degree %.1f)" % (time.time() - t0, counts.mean()))
+
+    g = pkg.GpuIndex(local_rank)
+    code_seed = args.seed + 7
+    t0 = time.time()
+    if world == 1:
+        g.upload_ivf_synthetic(d, M, tb["offsets"], centroid_norms, tb["pq_centroids"], tb["norm_table"], code_seed)
+    else:
+        ids_s, codes_s, ncodes_s = synth.synthetic_codes_shard(code_seed, tb["offsets"], M, rank, world)
+        g.upload_ivf(d, M, tb["offsets"], ids_s, codes_s, ncodes_s, centroid_norms, tb["pq_centroids"],
+                     tb["norm_table"], shard_rank=rank, shard_world=world)
+        del ids_s, codes_s, ncodes_s
+    g.upload_quantizer(counts, links, tb["centroids"], 0)
+    if rank == 0:
+        log("[bench] corpus on device: %.1fs, %.2f GB held" % (time.time() - t0, g.memory_bytes() / 1e9))
+
+    # everything the timed region touches lives in HBM already
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_q = torch.from_numpy(queries).to(dev)
+    d_dist = torch.empty((nq, 1), dtype=torch.float32, device=dev)
+    d_lab = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    d_keys = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    d_cid = torch.empty((nq, nprobe), dtype=torch.int32, device=dev)
+    d_cd = torch.empty((nq, nprobe), dtype=torch.float32, device=dev)
+
+    host_coarse = None
+    if args.host_coarse:
+        raise SystemExit("--host-coarse needs the oracle corpus; use the tests instead")
+
+    # query slices for the sharded coarse stage
+    per = (nq + world - 1) // world
+    q_lo, q_hi = min(rank * per, nq), min((rank + 1) * per, nq)
+    if world > 1:
+        d_cid_pad = torch.empty((per * world, nprobe), dtype=torch.int32, device=dev)
+        d_cd_pad = torch.empty((per * world, nprobe), dtype=torch.float32, device=dev)
+
+    def step():
+        if world == 1:
+            g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, efSearch=ef)
+            return
+        # 1. coarse walk for this rank's slice of the batch, 2. all-gather, 3. scan own shard for all queries,
+        # 4. MIN over shards of the packed keys, 5. owner resolves labels, MAX over shards
+        if q_hi > q_lo:
+            g.coarse_dev(q_hi - q_lo, d_q[q_lo:q_hi], nprobe, ef, d_cid_pad[rank * per:], d_cd_pad[rank * per:])
+        dist.all_gather_into_tensor(d_cid_pad, d_cid_pad[rank * per:(rank + 1) * per])
+        dist.all_gather_into_tensor(d_cd_pad, d_cd_pad[rank * per:(rank + 1) * per])
+        g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, d_coarse_ids=d_cid_pad, d_coarse_dists=d_cd_pad,
+                     d_out_keys=d_keys)
+        dist.all_reduce(d_keys, op=dist.ReduceOp.MIN)
+        g.resolve_keys_dev(nq, 1, d_keys, d_dist, d_lab)
+        dist.all_reduce(d_lab, op=dist.ReduceOp.MAX)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    g.set_profiling(True)
+    g.reset_stage_ms()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    stage = g.stage_ms()
+    g.set_profiling(False)
+    ncodes, nsegs = g.last_scan_counts()  # per step, this shard
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    nc_t = torch.tensor([float(ncodes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nc_t, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    ncodes_all = float(nc_t.item())
+
+    lab_gpu = d_lab.cpu().numpy()[:, 0]
+    dist_gpu = d_dist.cpu().numpy()[:, 0]
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = nq * args.steps / elapsed
+        scan_ms, scan_n = stage["scan"]
+        scan_avg_ms = scan_ms / max(1, scan_n)
+        bytes_per_code = M + 1  # PQ code + norm code
+        achieved = bytes_per_code * ncodes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+        out = {
+            "metric": "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak",
+            "value": round(qps, 1),
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": args.workload, "n_vectors": n_total, "nc": nc, "d": d, "code_size": M,
+                "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef, "batch": nq, "k": 1,
+                "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq, 1),
+                "sharding": "replicas=1" if world == 1 else "lists c%%%d, RCCL min-merge" % world,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "scan_k1_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_code": bytes_per_code, "codes_per_launch": ncodes, "avg_launch_ms": round(scan_avg_ms, 4),
+            },
+            "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
+        }
+
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle (a port of the reference's CPU path) on the same corpus, bounded sample of the same batch
+            from oracle import orc
+            t0 = time.time()
+            ids_h, codes_h, ncodes_h = synth.synthetic_codes(code_seed, tb["offsets"], M)
+            graph = orc.Hnsw.from_arrays(counts, links, tb["centroids"], 16, 0)
+            ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h, ncodes_h,
+                           centroid_norms)
+            ox.set_params(nprobe, max_codes, ef)
+            log("[bench] host corpus for the CPU baseline: %.1fs" % (time.time() - t0))
+            ncores = os.cpu_count() or 1
+            # serial, exactly how the reference drivers run it (tests/test_ivfhnsw_sift1b.cpp:193-208)
+            ns = min(nq, 1000)
+            ox.search_batch(queries[:32], 1, 1)
+            t0 = time.perf_counter()
+            rd, rl, _, _, st = ox.search_batch(queries[:ns], 1, 1)
+            t_serial = time.perf_counter() - t0
+            # all host cores, OpenMP over queries (an extension: the reference has no parallel search path)
+            reps = max(1, int(10.0 / max(1e-3, t_serial * (nq / ns) / ncores)))
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                rd_all, rl_all, _, _, _ = ox.search_batch(queries, 1, ncores)
+            t_par = (time.perf_counter() - t0) / reps
+            out["cpu_baseline"] = {
+                "value": round(nq / t_par, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
+                "sample": "%d x the full %d-query batch, OpenMP over queries on %d threads; serial (1 thread, first %d "
+                          "queries, as the reference drivers loop): %.1f queries/s" % (reps, nq, ncores, ns, ns / t_serial),
+                "serial_value": round(ns / t_serial, 1),
+            }
+            same_l = int((rl_all[:, 0] == lab_gpu).sum())
+            same_d = int((rd_all[:, 0].view(np.uint32) == dist_gpu.view(np.uint32)).sum())
+            out["parity"] = {"queries_checked": nq, "labels_equal": same_l, "distances_bit_equal": same_d}
+            if same_l != nq or same_d != nq:
+                log("[bench] PARITY FAILURE: %d/%d labels, %d/%d distances" % (same_l, nq, same_d, nq))
+        print(json.dumps(out), flush=True)
+
+    g.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if out is not None and "parity" in out and out["parity"]["labels_equal"] != out["parity"]["queries_checked"]:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

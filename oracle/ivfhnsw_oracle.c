@@ -30,26 +30,27 @@
  * sub/mul/add steps; TmpRes[0]+...+TmpRes[7] is summed left to right. */
 float orc_l2sqr(const float *x, const float *y, size_t d)
 {
-    float lane[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* one 8-wide vector accumulator == the 8 lanes; element-wise sub, mul, add, each rounded
+     * (built with -ffp-contract=off, so no step is fused) */
+    typedef float v8f __attribute__((vector_size(32), aligned(4)));
+    v8f acc = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t nblk = d >> 4;
     for (size_t b = 0; b < nblk; b++) {
         for (int half = 0; half < 2; half++) {
-            const float *xp = x + b * 16 + half * 8;
-            const float *yp = y + b * 16 + half * 8;
-            for (int l = 0; l < 8; l++) {
-                float diff = xp[l] - yp[l];
-                float sq = diff * diff;
-                lane[l] = lane[l] + sq;
-            }
+            v8f xv = *(const v8f *)(x + b * 16 + half * 8);
+            v8f yv = *(const v8f *)(y + b * 16 + half * 8);
+            v8f diff = xv - yv;
+            v8f sq = diff * diff;
+            acc = acc + sq;
         }
     }
-    float res = lane[0] + lane[1];
-    res = res + lane[2];
-    res = res + lane[3];
-    res = res + lane[4];
-    res = res + lane[5];
-    res = res + lane[6];
-    res = res + lane[7];
+    float res = acc[0] + acc[1];
+    res = res + acc[2];
+    res = res + acc[3];
+    res = res + acc[4];
+    res = res + acc[5];
+    res = res + acc[6];
+    res = res + acc[7];
     return res;
 }
 

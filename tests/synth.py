@@ -214,3 +214,76 @@ def synthetic_codes(seed, offsets, code_size):
     norm_codes = hash_bytes(int(np.uint64(seed) ^ NORM_SEED_XOR), 0, n)
     ids = np.arange(n, dtype=np.uint32)
     return ids, codes, norm_codes
+
+
+def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=8192):
+    """A navigable small-world graph for throughput runs: each node links to its M nearest neighbours, then
+    reverse links are added up to maxM (the same degree bounds the reference's construction keeps,
+    IndexIVF_HNSW.cpp:50, hnswalg.cpp:171-184).  The reference-identical serial construction (orc.Hnsw.build,
+    used by every parity test) would take minutes at 10^5-10^6 nodes; graph construction is outside the
+    search path so the throughput corpus uses this brute-force stand-in.  Returns
+    (counts u8 [n], links u32 [n, maxM])."""
+    import torch
+
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    x = torch.from_numpy(np.ascontiguousarray(centroids, np.float32)).to(dev)
+    n = x.shape[0]
+    sq = (x * x).sum(1)
+    knn = torch.empty((n, M), dtype=torch.int64, device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        dist = sq[s:e, None] - 2.0 * (x[s:e] @ x.T) + sq[None, :]
+        dist[torch.arange(e - s, device=dev), torch.arange(s, e, device=dev)] = float("inf")
+        knn[s:e] = dist.topk(M, dim=1, largest=False).indices
+    knn = knn.cpu().numpy().astype(np.uint32)
+    links = np.zeros((n, maxM), np.uint32)
+    links[:, :M] = knn
+    counts = np.full(n, M, np.int64)
+    # reverse edges, in order of the forward edge's rank (closest first), while room remains
+    # vectorised per rank: for rank r, add edge dst->src where dst has room and the edge is not already there
+    for r in range(M):
+        s_r = np.arange(n, dtype=np.uint32)
+        d_r = knn[:, r]
+        # skip when the reverse edge already exists as a forward edge of d_r
+        exists = (knn[d_r] == s_r[:, None]).any(1)
+        cand = np.nonzero(~exists)[0]
+        # several sources may target the same node in this round: take them in source order
+        tgt = d_r[cand]
+        o = np.argsort(tgt, kind="stable")
+        tgt, srcs = tgt[o], s_r[cand][o]
+        first = np.r_[True, tgt[1:] != tgt[:-1]]
+        rank_in_group = np.arange(len(tgt)) - np.maximum.accumulate(np.where(first, np.arange(len(tgt)), 0))
+        slot = counts[tgt] + rank_in_group
+        ok = slot < maxM
+        links[tgt[ok], slot[ok]] = srcs[ok]
+        np.add.at(counts, tgt[ok], 1)
+    return counts.astype(np.uint8), links
+
+
+def synthetic_codes_shard(seed, offsets, code_size, rank, world):
+    """The lists c % world == rank of the device's synthetic corpus (same bytes as the unsharded stream)."""
+    off = offsets.astype(np.int64)
+    nc = len(off) - 1
+    owned = np.arange(rank, nc, world)
+    sizes = off[owned + 1] - off[owned]
+    n = int(sizes.sum())
+    # global vector index of every owned vector
+    starts = np.repeat(off[owned], sizes)
+    within = np.arange(n, dtype=np.int64) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+    gidx = (starts + within).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        wpc = code_size // 8 if code_size % 8 == 0 else 0
+        if wpc:
+            w = (gidx[:, None] * np.uint64(wpc) + np.arange(wpc, dtype=np.uint64)[None, :]).reshape(-1)
+            v = _mix64(np.uint64(seed) + (w + np.uint64(1)) * GOLDEN)
+            codes = v.view(np.uint8).reshape(n, code_size)
+        else:  # code_size 4: half a word per code
+            w = gidx // np.uint64(2)
+            v = _mix64(np.uint64(seed) + (w + np.uint64(1)) * GOLDEN)
+            sh = (gidx % np.uint64(2)) * np.uint64(32)
+            codes = ((v >> sh) & np.uint64(0xffffffff)).astype(np.uint32).view(np.uint8).reshape(n, 4)
+        nseed = np.uint64(seed) ^ NORM_SEED_XOR
+        w = gidx // np.uint64(8)
+        v = _mix64(nseed + (w + np.uint64(1)) * GOLDEN)
+        norm_codes = ((v >> ((gidx % np.uint64(8)) * np.uint64(8))) & np.uint64(0xff)).astype(np.uint8)
+    return gidx.astype(np.uint32), np.ascontiguousarray(codes), norm_codes
