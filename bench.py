@@ -54,6 +54,7 @@ def main():
                     help="feed the oracle's coarse stage instead of running the HNSW walk on the device (debug)")
     args = ap.parse_args()
 
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # oracle threads must not spin inside a CPU quota
     import torch
     import torch.distributed as dist
 
@@ -151,6 +152,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t_start
+    if rank == 0:
+        log("[bench] timed region: %d steps in %.3fs" % (args.steps, elapsed))
     stage = g.stage_ms()
     g.set_profiling(False)
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
@@ -211,19 +214,26 @@ def main():
                            centroid_norms)
             ox.set_params(nprobe, max_codes, ef)
             log("[bench] host corpus for the CPU baseline: %.1fs" % (time.time() - t0))
-            ncores = os.cpu_count() or 1
+            # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only spin
+            try:
+                ncores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncores = os.cpu_count() or 1
+            ncores = max(1, min(ncores, int(os.environ.get("IVFHNSW_BENCH_CPU_THREADS", "16"))))
             # serial, exactly how the reference drivers run it (tests/test_ivfhnsw_sift1b.cpp:193-208)
             ns = min(nq, 1000)
             ox.search_batch(queries[:32], 1, 1)
             t0 = time.perf_counter()
             rd, rl, _, _, st = ox.search_batch(queries[:ns], 1, 1)
             t_serial = time.perf_counter() - t0
+            log("[bench] cpu serial: %d queries in %.2fs" % (ns, t_serial))
             # all host cores, OpenMP over queries (an extension: the reference has no parallel search path)
             reps = max(1, int(10.0 / max(1e-3, t_serial * (nq / ns) / ncores)))
             t0 = time.perf_counter()
             for _ in range(reps):
                 rd_all, rl_all, _, _, _ = ox.search_batch(queries, 1, ncores)
             t_par = (time.perf_counter() - t0) / reps
+            log("[bench] cpu openmp x%d: %d x %d queries, %.2fs each" % (ncores, reps, nq, t_par))
             out["cpu_baseline"] = {
                 "value": round(nq / t_par, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
                 "sample": "%d x the full %d-query batch, OpenMP over queries on %d threads; serial (1 thread, first %d "

@@ -620,7 +620,7 @@ int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_q
     {
         StageScope sc(h, IVFHNSW_STAGE_PLAN);
         if (h->has_group) {
-            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * sizeof(float))))
+            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
                 return rc;
             HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
                                          p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),

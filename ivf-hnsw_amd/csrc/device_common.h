@@ -1,0 +1,99 @@
+// Device helpers shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ivfhnsw_gpu_impl {
+
+// Exact reference distance (hnswlib/hnswalg.cpp:326-357 == utils.cpp:22-52, AVX branch): 8 accumulators
+// over blocks of 16 floats, unfused multiply then add, accumulators summed left to right.
+// `row` is this lane's vector in global memory, `sq` the query in LDS (uniform address -> broadcast).
+__device__ __forceinline__ float l2_ref_order(const float *__restrict__ row, const float *sq, int d)
+{
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    const float4 *r4 = reinterpret_cast<const float4 *>(row);
+    const float4 *q4 = reinterpret_cast<const float4 *>(sq);
+    for (int b = 0; b < d / 16; b++) {
+        const float4 y0 = r4[4 * b], y1 = r4[4 * b + 1], y2 = r4[4 * b + 2], y3 = r4[4 * b + 3];
+        const float4 x0 = q4[4 * b], x1 = q4[4 * b + 1], x2 = q4[4 * b + 2], x3 = q4[4 * b + 3];
+        float t;
+#define IVFHNSW_ACC(a, xv, yv) \
+    t = __fsub_rn(xv, yv);     \
+    a = __fadd_rn(a, __fmul_rn(t, t));
+        IVFHNSW_ACC(a0, x0.x, y0.x) IVFHNSW_ACC(a1, x0.y, y0.y) IVFHNSW_ACC(a2, x0.z, y0.z) IVFHNSW_ACC(a3, x0.w, y0.w)
+        IVFHNSW_ACC(a4, x1.x, y1.x) IVFHNSW_ACC(a5, x1.y, y1.y) IVFHNSW_ACC(a6, x1.z, y1.z) IVFHNSW_ACC(a7, x1.w, y1.w)
+        IVFHNSW_ACC(a0, x2.x, y2.x) IVFHNSW_ACC(a1, x2.y, y2.y) IVFHNSW_ACC(a2, x2.z, y2.z) IVFHNSW_ACC(a3, x2.w, y2.w)
+        IVFHNSW_ACC(a4, x3.x, y3.x) IVFHNSW_ACC(a5, x3.y, y3.y) IVFHNSW_ACC(a6, x3.z, y3.z) IVFHNSW_ACC(a7, x3.w, y3.w)
+#undef IVFHNSW_ACC
+    }
+    float r = __fadd_rn(a0, a1);
+    r = __fadd_rn(r, a2);
+    r = __fadd_rn(r, a3);
+    r = __fadd_rn(r, a4);
+    r = __fadd_rn(r, a5);
+    r = __fadd_rn(r, a6);
+    r = __fadd_rn(r, a7);
+    return r;
+}
+
+// inclusive prefix sum over the 64 lanes of a wavefront
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v += o;
+    }
+    return v;
+}
+
+// order-preserving map f32 -> u32 (and back) for packed (distance, scan position) keys
+__device__ __forceinline__ uint32_t f32_orderable(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float orderable_f32(uint32_t o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+
+template <int CS>
+__device__ __forceinline__ void load_code_words(const uint8_t *__restrict__ codes, uint32_t gi, uint32_t (&w)[CS / 4])
+{
+    const uint8_t *p = codes + (size_t)gi * CS;
+    if constexpr (CS % 16 == 0) {
+#pragma unroll
+        for (int i = 0; i < CS / 16; i++) {
+            uint4 v = reinterpret_cast<const uint4 *>(p)[i];
+            w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
+        }
+    } else if constexpr (CS % 8 == 0) {
+#pragma unroll
+        for (int i = 0; i < CS / 8; i++) {
+            uint2 v = reinterpret_cast<const uint2 *>(p)[i];
+            w[2 * i] = v.x, w[2 * i + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CS / 4; i++)
+            w[i] = reinterpret_cast<const uint32_t *>(p)[i];
+    }
+}
+
+// IndexIVF_HNSW.cpp:802-814: result starts at 0 and adds table entries for m = 0..CS-1 in order.
+template <int CS>
+__device__ __forceinline__ float adc_sum(const float *s_lut, const uint32_t (&w)[CS / 4])
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int m = 0; m < CS; m++) {
+        const uint32_t b = (w[m >> 2] >> ((m & 3) * 8)) & 0xffu;
+        sum = __fadd_rn(sum, s_lut[m * 256 + b]);
+    }
+    return sum;
+}
+
+} // namespace ivfhnsw_gpu_impl

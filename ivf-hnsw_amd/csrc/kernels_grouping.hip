@@ -1,7 +1,179 @@
-// placeholder: Grouping plan kernel (written next)
+// Scan plan of IndexIVF_HNSW_Grouping::search (IndexIVF_HNSW_Grouping.cpp:222-353): sub-centroid
+// distances, pruning threshold (pass 1) and the list of sub-groups to score with their constant
+// term1 + term2 (pass 2).  One wavefront per query; lanes run over the nsubc sub-groups of a probe.
+//
+// The reference evaluates ||x - y_N||^2 lazily through a per-query cache (Grouping.cpp:244-250,
+// 311-316); the cached value is a pure function of (query, centroid) -- the HNSW walk and fvec_L2sqr are
+// the same arithmetic (utils.cpp:22-52 == hnswalg.cpp:326-357) -- so it is simply evaluated where needed.
+// Sequential float sums (the threshold, Grouping.cpp:253) keep the reference's (probe, sub-group) order.
 #include "ivfhnsw_kernels.h"
+#include "device_common.h"
+
 namespace ivfhnsw_gpu_impl {
-hipError_t launch_plan_grouping(hipStream_t, const IvfTables &, const GroupTables &, const GraphTables &,
-                                const float *, const uint32_t *, const float *, int, int, uint64_t, int, Seg *,
-                                uint32_t *, PlanHdr *, int, uint64_t *, int, float *) { return hipErrorNotSupported; }
+
+// scratch per query: qsd[max_seg] (pass-1 values, row-major [row][subc]) | qn[max_seg] (distances)
+__global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTables g, GraphTables gr,
+                                                           const float *__restrict__ xq,
+                                                           const uint32_t *__restrict__ cid,
+                                                           const float *__restrict__ cd, int nq, int nprobe,
+                                                           unsigned long long max_codes, int do_pruning,
+                                                           Seg *__restrict__ segs, uint32_t *__restrict__ lpos,
+                                                           PlanHdr *__restrict__ hdr, int max_seg,
+                                                           unsigned long long *__restrict__ keys, int k,
+                                                           float *__restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x;
+    const int nsubc = g.nsubc;
+    for (int j = lane; j < k; j += 64)
+        keys[(size_t)q * k + j] = kKeyInit;
+    for (int i = lane; i < t.d; i += 64)
+        s_q[i] = xq[(size_t)q * t.d + i];
+    __syncthreads();
+
+    float *qsd = scratch + (size_t)q * 2 * max_seg;
+    float *qnv = qsd + max_seg;
+    const uint32_t *qc = cid + (size_t)q * nprobe;
+    const float *qd = cd + (size_t)q * nprobe;
+
+    // ---- pass 1 (Grouping.cpp:222-262)
+    float threshold = 0.0f;
+    int p1_rows = 0;
+    if (do_pruning) {
+        unsigned long long ncode = 0;
+        unsigned long long nsubgroups = 0;
+        int row = 0;
+        for (int i = 0; i < nprobe; i++) {
+            const uint32_t c = qc[i];
+            if (c >= t.nc)
+                continue;
+            const unsigned long long gs = t.goff[c + 1] - t.goff[c];
+            if (gs == 0)
+                continue;
+            const float alpha = g.alphas[c];
+            const float oma = __fsub_rn(1.0f, alpha);
+            const float term1 = __fmul_rn(oma, qd[i]);
+            for (int s0 = 0; s0 < nsubc; s0 += 64) {
+                const int subc = s0 + lane;
+                bool active = false;
+                float v = 0.f, qn = 0.f;
+                if (subc < nsubc && g.sub_sizes[(size_t)c * nsubc + subc] != 0) {
+                    active = true;
+                    const uint32_t nn = g.nn_idx[(size_t)c * nsubc + subc];
+                    qn = l2_ref_order(gr.vectors + (size_t)nn * t.d, s_q, t.d);
+                    const float a = __fmul_rn(oma, g.inter_dists[(size_t)c * nsubc + subc]);
+                    const float b = __fsub_rn(a, qn);
+                    v = __fsub_rn(term1, __fmul_rn(alpha, b)); // Grouping.cpp:251-252
+                }
+                if (subc < nsubc) {
+                    qsd[(size_t)row * nsubc + subc] = v; // value-initialised 0.0 where inactive (:228)
+                    qnv[(size_t)row * nsubc + subc] = qn;
+                }
+                unsigned long long m = __ballot(active);
+                nsubgroups += __popcll(m);
+                while (m) { // threshold += qsd[subc], in sub-group order (:253)
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    threshold = __fadd_rn(threshold, __shfl(v, j, 64));
+                }
+            }
+            ncode += gs;
+            row++;
+            if (ncode >= 2 * max_codes)
+                break;
+        }
+        p1_rows = row;
+        threshold = __fdiv_rn(threshold, (float)nsubgroups); // :261, 0/0 = NaN when nothing was seen
+    }
+    __syncthreads();
+
+    // ---- pass 2 (Grouping.cpp:283-353)
+    unsigned long long ncode = 0; // codes scored so far == scan position of the next one
+    uint32_t ns = 0, nl = 0;
+    int row = 0;
+    Seg *sq = segs + (size_t)q * max_seg;
+    uint32_t *lq = lpos + (size_t)q * max_seg;
+    for (int i = 0; i < nprobe; i++) {
+        const uint32_t c = qc[i];
+        if (c >= t.nc)
+            continue;
+        const unsigned long long gs = t.goff[c + 1] - t.goff[c];
+        if (gs == 0)
+            continue;
+        const float alpha = g.alphas[c];
+        const float oma = __fsub_rn(1.0f, alpha);
+        const float term1 = __fmul_rn(oma, __fsub_rn(qd[i], t.centroid_norms[c]));
+        const bool owned = (c % t.shard_world) == t.shard_rank;
+        uint32_t list_off = 0; // codes of this list before the current chunk of sub-groups
+        for (int s0 = 0; s0 < nsubc; s0 += 64) {
+            const int subc = s0 + lane;
+            uint32_t sz = 0;
+            bool scanned = false;
+            float cterm = 0.f;
+            if (subc < nsubc)
+                sz = g.sub_sizes[(size_t)c * nsubc + subc];
+            if (sz != 0) {
+                float qs = 0.0f;
+                if (do_pruning && row < p1_rows)
+                    qs = qsd[(size_t)row * nsubc + subc];
+                scanned = !do_pruning || qs < threshold; // :308
+                if (scanned) {
+                    const uint32_t nn = g.nn_idx[(size_t)c * nsubc + subc];
+                    float qn;
+                    if (do_pruning && row < p1_rows)
+                        qn = qnv[(size_t)row * nsubc + subc];
+                    else
+                        qn = l2_ref_order(gr.vectors + (size_t)nn * t.d, s_q, t.d);
+                    const float term2 = __fmul_rn(alpha, __fsub_rn(qn, t.centroid_norms[nn])); // :318
+                    cterm = __fadd_rn(term1, term2);
+                }
+            }
+            const uint32_t in_sz = wave_incl_scan(sz, lane);
+            const uint32_t in_sc = wave_incl_scan(scanned ? sz : 0u, lane);
+            const unsigned long long m = __ballot(scanned);
+            const uint32_t rank_sc = __popcll(m & ((1ull << lane) - 1ull));
+            if (scanned && owned) {
+                Seg sg;
+                sg.start = t.loff[c] + list_off + (in_sz - sz);
+                sg.len = sz;
+                sg.vpos = (uint32_t)ncode + (in_sc - sz);
+                sg.cterm = cterm;
+                sq[ns + rank_sc] = sg;
+                lq[ns + rank_sc] = nl + (in_sc - sz);
+            }
+            const uint32_t tot_sz = __shfl(in_sz, 63, 64), tot_sc = __shfl(in_sc, 63, 64);
+            list_off += tot_sz;
+            ncode += tot_sc;
+            if (owned) {
+                ns += (uint32_t)__popcll(m);
+                nl += tot_sc;
+            }
+        }
+        if (ncode >= max_codes)
+            break;
+        if (do_pruning)
+            row++;
+    }
+    if (lane == 0) {
+        PlanHdr h;
+        h.nseg = ns;
+        h.total = nl;
+        hdr[q] = h;
+    }
 }
+
+hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
+                                const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
+                                int nprobe, uint64_t max_codes, int do_pruning, Seg *segs, uint32_t *lpos,
+                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *scratch)
+{
+    if (nq == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), t.d * sizeof(float), s, t, g, gr, xq, coarse_ids,
+                       coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr, max_seg,
+                       reinterpret_cast<unsigned long long *>(keys), k, scratch);
+    return hipGetLastError();
+}
+
+} // namespace ivfhnsw_gpu_impl

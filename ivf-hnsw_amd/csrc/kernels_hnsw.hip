@@ -20,6 +20,7 @@
 // Bound: latency of dependent HBM/L2 round trips (links -> bitmap -> vectors), hidden by running one
 // query per resident wavefront slot.
 #include "ivfhnsw_kernels.h"
+#include "device_common.h"
 
 #include <float.h>
 
@@ -28,36 +29,6 @@ namespace ivfhnsw_gpu_impl {
 namespace {
 
 constexpr int kTailCap = 64;
-
-// Exact reference distance (hnswalg.cpp:326-357): 8 accumulators over blocks of 16, unfused, lanes
-// summed left to right.  `sq` is the query in LDS (uniform address -> broadcast reads).
-__device__ __forceinline__ float l2_ref_order(const float *__restrict__ row, const float *sq, int d)
-{
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-    const float4 *r4 = reinterpret_cast<const float4 *>(row);
-    const float4 *q4 = reinterpret_cast<const float4 *>(sq);
-    for (int b = 0; b < d / 16; b++) {
-        const float4 y0 = r4[4 * b], y1 = r4[4 * b + 1], y2 = r4[4 * b + 2], y3 = r4[4 * b + 3];
-        const float4 x0 = q4[4 * b], x1 = q4[4 * b + 1], x2 = q4[4 * b + 2], x3 = q4[4 * b + 3];
-        float t;
-#define ACC(a, xv, yv)              \
-    t = __fsub_rn(xv, yv);          \
-    a = __fadd_rn(a, __fmul_rn(t, t));
-        ACC(a0, x0.x, y0.x) ACC(a1, x0.y, y0.y) ACC(a2, x0.z, y0.z) ACC(a3, x0.w, y0.w)
-        ACC(a4, x1.x, y1.x) ACC(a5, x1.y, y1.y) ACC(a6, x1.z, y1.z) ACC(a7, x1.w, y1.w)
-        ACC(a0, x2.x, y2.x) ACC(a1, x2.y, y2.y) ACC(a2, x2.z, y2.z) ACC(a3, x2.w, y2.w)
-        ACC(a4, x3.x, y3.x) ACC(a5, x3.y, y3.y) ACC(a6, x3.z, y3.z) ACC(a7, x3.w, y3.w)
-#undef ACC
-    }
-    float r = __fadd_rn(a0, a1);
-    r = __fadd_rn(r, a2);
-    r = __fadd_rn(r, a3);
-    r = __fadd_rn(r, a4);
-    r = __fadd_rn(r, a5);
-    r = __fadd_rn(r, a6);
-    r = __fadd_rn(r, a7);
-    return r;
-}
 
 // key = dist bits (non-negative float: bit order == value order) : id : expanded flag
 __device__ __forceinline__ unsigned long long mk_key(float dist, uint32_t id)

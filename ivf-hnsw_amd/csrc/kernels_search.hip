@@ -5,21 +5,12 @@
 // intrinsic in the order the reference's source evaluates it; this file is built with
 // -ffp-contract=off so nothing else gets fused either.
 #include "ivfhnsw_kernels.h"
+#include "device_common.h"
 
 #include <float.h>
 #include <algorithm>
 
 namespace ivfhnsw_gpu_impl {
-
-__device__ __forceinline__ uint32_t f32_orderable(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float orderable_f32(uint32_t o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
 
 // ---------------------------------------------------------------------------------------------
 // OPQ rotation: y[q][i] = sum_k A[i][k] x[q][k] as a k-ordered fmaf chain (reference call site
@@ -205,42 +196,6 @@ hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *co
 // Bound: HBM read of CS+1 bytes per code; the CS LDS gathers per code run at about the same rate
 // (random bank conflicts), see DESIGN.md.
 // ---------------------------------------------------------------------------------------------
-template <int CS>
-__device__ __forceinline__ void load_code_words(const uint8_t *__restrict__ codes, uint32_t gi, uint32_t (&w)[CS / 4])
-{
-    const uint8_t *p = codes + (size_t)gi * CS;
-    if constexpr (CS % 16 == 0) {
-#pragma unroll
-        for (int i = 0; i < CS / 16; i++) {
-            uint4 v = reinterpret_cast<const uint4 *>(p)[i];
-            w[4 * i] = v.x, w[4 * i + 1] = v.y, w[4 * i + 2] = v.z, w[4 * i + 3] = v.w;
-        }
-    } else if constexpr (CS % 8 == 0) {
-#pragma unroll
-        for (int i = 0; i < CS / 8; i++) {
-            uint2 v = reinterpret_cast<const uint2 *>(p)[i];
-            w[2 * i] = v.x, w[2 * i + 1] = v.y;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < CS / 4; i++)
-            w[i] = reinterpret_cast<const uint32_t *>(p)[i];
-    }
-}
-
-// IndexIVF_HNSW.cpp:802-814: result starts at 0 and adds table entries for m = 0..CS-1 in order.
-template <int CS>
-__device__ __forceinline__ float adc_sum(const float *s_lut, const uint32_t (&w)[CS / 4])
-{
-    float sum = 0.0f;
-#pragma unroll
-    for (int m = 0; m < CS; m++) {
-        const uint32_t b = (w[m >> 2] >> ((m & 3) * 8)) & 0xffu;
-        sum = __fadd_rn(sum, s_lut[m * 256 + b]);
-    }
-    return sum;
-}
-
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
 {
 #pragma unroll
