@@ -299,7 +299,7 @@ int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
         return fail(IVFHNSW_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
     }
     h->own_stream = true;
-    if (h->w_status.ensure(sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, sizeof(uint32_t)) != hipSuccess) {
+    if (h->w_status.ensure(2 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
         ivfhnsw_gpu_destroy(h);
         return fail(IVFHNSW_ERR_HIP, "cannot allocate the device status word");
     }
@@ -511,13 +511,14 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
     if (nq > 0x7fffffffull)
         return fail(IVFHNSW_ERR_INVALID, "nq too large");
     // one visited bitmap per resident wavefront slot
-    const size_t words = ((size_t)h->gr.n + 31) / 32;
-    const int nslots = (int)std::min<size_t>(nq, 256 * 8);
+    const size_t words = ((((size_t)h->gr.n + 31) / 32) + 3) & ~(size_t)3;
+    const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
     if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
         return rc;
     StageScope sc(h, IVFHNSW_STAGE_COARSE);
     HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>()));
+                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
+                          h->w_status.as<uint32_t>() + 1));
     return IVFHNSW_OK;
 }
 

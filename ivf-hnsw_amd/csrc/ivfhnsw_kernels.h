@@ -89,7 +89,8 @@ hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, co
 // HNSW walk, one wavefront per query (hnswalg.cpp:48-109,227-234)
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                         size_t visited_words_per_slot, int nslots, uint32_t *status);
+                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query);
+int coarse_slots_for(int ef);
 // bits of the device status word
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index

@@ -4,25 +4,28 @@
 //
 // The reference walks with two std::priority_queue<pair<float,idx_t>>: `topResults` (max-heap, <= ef
 // entries) and `candidateSet` (min-heap by negated distance).  Both are replaced here by ONE array R
-// sorted ascending by (dist, id), held in LDS, each entry carrying an "expanded" bit:
+// sorted ascending by (dist, id), each entry carrying an "expanded" bit, DISTRIBUTED OVER THE LANES'
+// REGISTERS (entry i lives in lane i % 64, register i / 64), so that selecting the next candidate,
+// testing admission and inserting are ballots, readlanes and one-lane DPP shifts -- no memory at all:
 //   * topResults            = R itself (its maximum is R[n-1]);
 //   * candidateSet's top    = the not-yet-expanded entry of smallest distance (largest id among equal
 //                             distances, as pair<-dist,id> orders them).  A candidate that was evicted
 //                             from topResults can only still be popped if its distance EQUALS the
 //                             current lowerBound (hnswalg.cpp:67 breaks on '>'), so evicted entries are
-//                             kept in a small `tail` while that equality holds and dropped otherwise.
+//                             kept in a small LDS `tail` while that equality holds and dropped otherwise.
 // Results are therefore identical to the reference's for any input, ties included.
 //
-// Per expansion: lanes read the node's <= maxM links (coalesced), test-and-set the visited bitmap
-// with one returning atomicOr each, lane j evaluates the exact 8-accumulator L2 distance
-// (hnswalg.cpp:326-357) of neighbour j, then admissions (hnswalg.cpp:93-103) are applied in link order
-// with wave-parallel sorted insertion.
-// Bound: latency of dependent HBM/L2 round trips (links -> bitmap -> vectors), hidden by running one
-// query per resident wavefront slot.
+// Per expansion: lanes read the node's link count and <= maxM links (coalesced), test-and-set the
+// visited bitmap with one returning atomicOr each, lane j evaluates the exact 8-accumulator L2 distance
+// (hnswalg.cpp:326-357) of neighbour j, then admissions (hnswalg.cpp:93-103) are applied in link order.
+// Bound: latency of the dependent round trips (links -> bitmap -> vectors) and the bandwidth of the
+// gathered 4*d-byte rows; hidden by keeping one query per resident wavefront (queries are handed out
+// through an atomic counter).
 #include "ivfhnsw_kernels.h"
 #include "device_common.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace ivfhnsw_gpu_impl {
 
@@ -38,76 +41,160 @@ __device__ __forceinline__ unsigned long long mk_key(float dist, uint32_t id)
 __device__ __forceinline__ uint32_t key_dist_bits(unsigned long long k) { return (uint32_t)(k >> 32); }
 __device__ __forceinline__ uint32_t key_id(unsigned long long k) { return (uint32_t)(k & 0xffffffffu) >> 1; }
 
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// value of the lane below (lane 0 gets its own value back)
+__device__ __forceinline__ unsigned long long lane_below_u64(unsigned long long v)
+{
+    // DPP wave_shr:1 (0x138): every lane reads lane-1 across the whole wavefront
+    const int lo = __builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const int hi =
+        __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+template <int NCH> struct RSet {
+    unsigned long long r[NCH]; // entry i: lane i & 63, register i >> 6
+
+    __device__ __forceinline__ unsigned long long get(int idx) const // idx wave-uniform
+    {
+        const int c = idx >> 6, l = __builtin_amdgcn_readfirstlane(idx & 63);
+        unsigned long long v = 0;
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++)
+            if (cc == c)
+                v = readlane_u64(r[cc], l);
+        return v;
+    }
+    __device__ __forceinline__ void mark_expanded(int idx, int lane)
+    {
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++)
+            if (cc == (idx >> 6) && lane == (idx & 63))
+                r[cc] |= 1ull;
+    }
+    // first not-yet-expanded entry among the first n, or -1
+    __device__ __forceinline__ int first_unexpanded(int n, int lane) const
+    {
+        int first = -1;
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++) {
+            const unsigned long long m = __ballot(cc * 64 + lane < n && !(r[cc] & 1ull));
+            if (m && first < 0)
+                first = cc * 64 + (__ffsll((long long)m) - 1);
+        }
+        return first;
+    }
+    // last not-yet-expanded entry with distance bits db at index >= first
+    __device__ __forceinline__ int last_unexpanded_with(uint32_t db, int first, int n, int lane) const
+    {
+        int last = first;
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++) {
+            const int i = cc * 64 + lane;
+            const unsigned long long m =
+                __ballot(i < n && i >= first && key_dist_bits(r[cc]) == db && !(r[cc] & 1ull));
+            if (m)
+                last = cc * 64 + (63 - __clzll((long long)m));
+        }
+        return last;
+    }
+    // number of entries among the first n whose (dist, id) is below K
+    __device__ __forceinline__ int rank_of(unsigned long long K, int n, int lane) const
+    {
+        int pos = 0;
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++)
+            pos += __popcll(__ballot(cc * 64 + lane < n && (r[cc] & ~1ull) < K));
+        return pos;
+    }
+    // insert K at sorted position pos, shifting the entries above it up by one (the last one falls off
+    // when the set is full: the caller read it first)
+    __device__ __forceinline__ void insert_at(unsigned long long K, int pos, int lane)
+    {
+#pragma unroll
+        for (int cc = NCH - 1; cc >= 0; cc--) {
+            unsigned long long below = lane_below_u64(r[cc]);
+            if (cc > 0) {
+                const unsigned long long carry = readlane_u64(r[cc - 1], 63);
+                if (lane == 0)
+                    below = carry;
+            }
+            const int i = cc * 64 + lane;
+            r[cc] = i < pos ? r[cc] : (i == pos ? K : below);
+        }
+    }
+};
+
 } // namespace
 
-// One wavefront (64-thread block) per slot; slot s walks queries s, s + nslots, ...
-// dynamic LDS: float query[d] | u64 R[efc + 1] | u64 tail[kTailCap]
-__global__ __launch_bounds__(64) void hnsw_walk_kernel(GraphTables g, const float *__restrict__ xq, int nq, int nprobe,
-                                                       int ef, int efc, uint32_t *__restrict__ coarse_ids,
+// One wavefront (64-thread block) per resident slot; queries are taken from an atomic counter.
+// dynamic LDS: float query[d] | u64 tail[kTailCap]
+template <int NCH, int MINW>
+__global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, const float *__restrict__ xq, int nq, int nprobe,
+                                                       int ef, uint32_t *__restrict__ coarse_ids,
                                                        float *__restrict__ coarse_dists,
                                                        uint32_t *__restrict__ visited, size_t vwords,
-                                                       uint32_t *__restrict__ status)
+                                                       uint32_t *__restrict__ status, uint32_t *__restrict__ next_query)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_q = reinterpret_cast<float *>(smem);
-    unsigned long long *R = reinterpret_cast<unsigned long long *>(smem + (size_t)g.d * sizeof(float));
-    unsigned long long *tail = R + efc + 1;
+    unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem + (size_t)g.d * sizeof(float));
 
     const int lane = threadIdx.x;
-    const int nchunk = efc / 64;
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
 
-    for (int q = blockIdx.x; q < nq; q += gridDim.x) {
+    for (;;) {
+        int q = 0;
+        if (lane == 0)
+            q = (int)atomicAdd(next_query, 1u);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= nq)
+            break;
+
         // reset the visited bitmap (visited_list_pool.h:25-32 does it by epoch) and stage the query
-        for (size_t w = lane; w < vwords; w += 64)
-            bm[w] = 0u;
+        {
+            uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+            const size_t v4 = vwords / 4; // vwords is padded to a multiple of 4
+            for (size_t w = lane; w < v4; w += 64)
+                bm4[w] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads(); // the previous query's readers of s_q are done
         for (int i = lane; i < g.d; i += 64)
             s_q[i] = xq[(size_t)q * g.d + i];
-        __syncthreads();
+        __syncthreads(); // also orders the bitmap reset before the atomics below
 
-        int n = 0;     // entries in R (== topResults.size())
+        RSet<NCH> R;
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++)
+            R.r[cc] = ~0ull;
+        int n = 1;     // entries in R (== topResults.size())
         int ntail = 0; // evicted entries whose distance still equals the lower bound
         {
             // hnswalg.cpp:56-62: seed with the enter point
             const float d0 = l2_ref_order(g.vectors + (size_t)g.enterpoint * g.d, s_q, g.d);
             if (lane == 0) {
-                R[0] = mk_key(d0, g.enterpoint);
-                bm[g.enterpoint >> 5] = 1u << (g.enterpoint & 31);
+                R.r[0] = mk_key(d0, g.enterpoint);
+                atomicOr(&bm[g.enterpoint >> 5], 1u << (g.enterpoint & 31));
             }
-            n = 1;
         }
-        __syncthreads();
 
         for (;;) {
             // ---- candidateSet.top(): first unexpanded entry of R, ties -> largest id; tail joins at dist == max
-            int first = -1;
-            for (int c = 0; c < nchunk && first < 0; c++) {
-                const int i = c * 64 + lane;
-                const bool un = i < n && !(R[i] & 1ull);
-                const unsigned long long m = __ballot(un);
-                if (m)
-                    first = c * 64 + (__ffsll((long long)m) - 1);
-            }
-            const uint32_t maxbits = key_dist_bits(R[n - 1]);
-            int pick = -1;          // index in R, or
-            int pick_tail = -1;     // index in tail
+            const int first = R.first_unexpanded(n, lane);
+            const uint32_t maxbits = key_dist_bits(R.get(n - 1));
+            int pick = -1;      // index in R, or
+            int pick_tail = -1; // index in tail
             uint32_t pick_id = 0;
             if (first >= 0) {
-                const uint32_t db = key_dist_bits(R[first]);
-                // last unexpanded entry with the same distance (the run is contiguous in R)
-                int last = first;
-                for (int c = first / 64; c < nchunk; c++) {
-                    const int i = c * 64 + lane;
-                    const bool hit = i < n && i >= first && key_dist_bits(R[i]) == db && !(R[i] & 1ull);
-                    const unsigned long long m = __ballot(hit);
-                    if (m)
-                        last = c * 64 + (63 - __clzll((long long)m));
-                    const bool beyond = i < n && key_dist_bits(R[i]) > db;
-                    if (__ballot(beyond))
-                        break;
-                }
-                pick = last;
-                pick_id = key_id(R[last]);
+                const uint32_t db = key_dist_bits(R.get(first));
+                pick = R.last_unexpanded_with(db, first, n, lane);
+                pick_id = key_id(R.get(pick));
                 if (db == maxbits && ntail > 0) {
                     // tail entries share this distance; the larger id pops first
                     for (int t = 0; t < ntail; t++)
@@ -129,25 +216,25 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(GraphTables g, const floa
             } else {
                 break; // candidateSet exhausted (hnswalg.cpp:64) or only entries beyond lowerBound left (:67)
             }
-            __syncthreads();
-            if (lane == 0) {
-                if (pick >= 0)
-                    R[pick] |= 1ull;
-                else
+            if (pick >= 0) {
+                R.mark_expanded(pick, lane);
+            } else {
+                __syncthreads();
+                if (lane == 0)
                     tail[pick_tail] = tail[ntail - 1];
-            }
-            if (pick < 0)
                 ntail--;
-            __syncthreads();
+                __syncthreads();
+            }
 
             // ---- expand: links, visited test-and-set, distances (hnswalg.cpp:72-91)
             const uint32_t node = pick_id;
             const int cnt = g.counts[node];
             uint32_t nb = 0;
+            if (lane < g.maxM)
+                nb = g.links[(size_t)node * g.maxM + lane]; // issued together with the count
             bool fresh = false;
             float dist = 0.f;
             if (lane < cnt) {
-                nb = g.links[(size_t)node * g.maxM + lane];
                 const uint32_t bit = 1u << (nb & 31);
                 const uint32_t old = atomicOr(&bm[nb >> 5], bit);
                 fresh = !(old & bit);
@@ -160,88 +247,96 @@ __global__ __launch_bounds__(64) void hnsw_walk_kernel(GraphTables g, const floa
             while (todo) {
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                const float dj = __shfl(dist, j, 64);
-                const uint32_t idj = __shfl(nb, j, 64);
-                const unsigned long long topk = R[n - 1];
+                const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), j));
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nb, j);
+                const unsigned long long topk = R.get(n - 1);
                 const float topd = __uint_as_float(key_dist_bits(topk));
                 if (!(topd > dj || n < ef))
                     continue;
                 const unsigned long long K = mk_key(dj, idj);
-                // position = number of entries with (dist,id) below K (flag bit masked out)
-                int pos = 0;
-                unsigned long long v[16];
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    if (c < nchunk) {
-                        const int i = c * 64 + lane;
-                        v[c] = i < n ? R[i] : ~0ull;
-                        pos += __popcll(__ballot(i < n && (v[c] & ~1ull) < K));
-                    }
-                }
-                __syncthreads();
+                const int pos = R.rank_of(K, n, lane);
                 const bool full = n == ef;
-                const unsigned long long evicted = R[n - 1];
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    if (c < nchunk) {
-                        const int i = c * 64 + lane;
-                        if (i < n && i >= pos && i + 1 < ef)
-                            R[i + 1] = v[c];
-                    }
-                }
-                if (lane == 0)
-                    R[pos] = K;
-                __syncthreads();
+                R.insert_at(K, pos, lane);
                 if (!full)
                     n++;
                 // bookkeeping of candidates that left topResults but may still be popped
-                const uint32_t newmax = key_dist_bits(R[n - 1]);
+                const uint32_t newmax = key_dist_bits(R.get(n - 1));
                 if (ntail > 0 && key_dist_bits(tail[0]) != newmax)
                     ntail = 0; // lower bound moved below them: dead for good
-                if (full && !(evicted & 1ull) && key_dist_bits(evicted) == newmax) {
+                if (full && !(topk & 1ull) && key_dist_bits(topk) == newmax) {
                     if (ntail < kTailCap) {
+                        __syncthreads();
                         if (lane == 0)
-                            tail[ntail] = evicted;
+                            tail[ntail] = topk;
                         ntail++;
+                        __syncthreads();
                     } else {
                         // more than kTailCap exact distance ties at the boundary: cannot be represented
                         if (lane == 0)
                             atomicOr(status, kStatusHnswTieOverflow);
                         ntail = -1;
+                        break;
                     }
-                    __syncthreads();
                 }
-                if (ntail < 0)
-                    break;
             }
             if (ntail < 0)
                 break;
         }
 
         // searchKnn pops down to nprobe (hnswalg.cpp:229-233); IndexIVF_HNSW.cpp:249-259 unloads nearest first
-        {
-            for (int i = lane; i < nprobe; i += 64) {
+#pragma unroll
+        for (int cc = 0; cc < NCH; cc++) {
+            const int i = cc * 64 + lane;
+            if (i < nprobe) {
                 const bool have = ntail >= 0 && i < n;
-                coarse_ids[(size_t)q * nprobe + i] = have ? key_id(R[i]) : 0xffffffffu;
-                coarse_dists[(size_t)q * nprobe + i] = have ? __uint_as_float(key_dist_bits(R[i])) : 0.f;
+                coarse_ids[(size_t)q * nprobe + i] = have ? key_id(R.r[cc]) : 0xffffffffu;
+                coarse_dists[(size_t)q * nprobe + i] = have ? __uint_as_float(key_dist_bits(R.r[cc])) : 0.f;
             }
         }
-        __syncthreads();
     }
+}
+
+// how many wavefront slots the walk keeps resident for a given ef (sizes the visited bitmaps)
+int coarse_slots_for(int ef)
+{
+    const int nch = (ef + 63) / 64;
+    const int waves_per_simd = nch <= 4 ? 8 : (nch <= 8 ? 5 : 3);
+    return 256 * 4 * waves_per_simd;
 }
 
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                         size_t visited_words_per_slot, int nslots, uint32_t *status)
+                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query)
 {
     if (nq == 0)
         return hipSuccess;
-    if (ef > 1024 || ef < 1 || g.maxM > 64 || g.n >= 0x80000000u)
+    if (ef > 1024 || ef < 1 || nprobe > ef || g.maxM > 64 || g.n >= 0x80000000u || (visited_words_per_slot & 3))
         return hipErrorInvalidValue;
-    const int efc = ((ef + 63) / 64) * 64;
-    const size_t shm = (size_t)g.d * sizeof(float) + (size_t)(efc + 1 + kTailCap) * sizeof(unsigned long long);
-    hipLaunchKernelGGL(hnsw_walk_kernel, dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef, efc, coarse_ids,
-                       coarse_dists, visited_scratch, visited_words_per_slot, status);
+    hipError_t e = hipMemsetAsync(next_query, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess)
+        return e;
+    const size_t shm = (size_t)g.d * sizeof(float) + (size_t)kTailCap * sizeof(unsigned long long);
+    const int nch = (ef + 63) / 64;
+#define IVFHNSW_WALK(N, W)                                                                                          \
+    hipLaunchKernelGGL((hnsw_walk_kernel<N, W>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef, coarse_ids, \
+                       coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
+    // tuning knob (A/B on the device): 8 waves/SIMD with a few spilled registers vs 5 without
+    static const bool occ8 = [] {
+        const char *e = getenv("IVFHNSW_WALK_OCC");
+        return !(e && atoi(e) < 8);
+    }();
+    if (nch <= 1) {
+        if (occ8) IVFHNSW_WALK(1, 8); else IVFHNSW_WALK(1, 4);
+    } else if (nch <= 2) {
+        if (occ8) IVFHNSW_WALK(2, 8); else IVFHNSW_WALK(2, 4);
+    } else if (nch <= 4) {
+        if (occ8) IVFHNSW_WALK(4, 8); else IVFHNSW_WALK(4, 4);
+    } else if (nch <= 8) {
+        IVFHNSW_WALK(8, 4);
+    } else {
+        IVFHNSW_WALK(16, 4);
+    }
+#undef IVFHNSW_WALK
     return hipGetLastError();
 }
 
