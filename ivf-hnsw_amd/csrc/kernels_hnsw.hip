@@ -16,8 +16,10 @@
 // Results are therefore identical to the reference's for any input, ties included.
 //
 // Per expansion: lanes read the node's link count and <= maxM links (coalesced), test-and-set the
-// visited bitmap with one returning atomicOr each, lane j evaluates the exact 8-accumulator L2 distance
-// (hnswalg.cpp:326-357) of neighbour j, then admissions (hnswalg.cpp:93-103) are applied in link order.
+// visited bitmap with one returning atomicOr each; the not-yet-visited neighbours are compacted and a
+// quad of lanes evaluates the exact 8-accumulator L2 distance (hnswalg.cpp:326-357) of each, 16 rows per
+// pass with all of a row's loads in flight at once; then admissions (hnswalg.cpp:93-103) are applied in
+// link order.
 // Bound: latency of the dependent round trips (links -> bitmap -> vectors) and the bandwidth of the
 // gathered 4*d-byte rows; hidden by keeping one query per resident wavefront (queries are handed out
 // through an atomic counter).
@@ -56,6 +58,56 @@ __device__ __forceinline__ unsigned long long lane_below_u64(unsigned long long 
     const int hi =
         __builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
     return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// position of the r-th (0-based) set bit of mask; r < popcount(mask)
+__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int r)
+{
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const int c = __popcll(mask & (((1ull << w) - 1ull) << pos));
+        if (c <= r) {
+            r -= c;
+            pos += w;
+        }
+    }
+    return pos;
+}
+
+// broadcast lane k of each quad to the whole quad (DPP quad_perm, no LDS)
+template <int K> __device__ __forceinline__ float quad_bcast(float v)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), K * 0x55, 0xf, 0xf, true));
+}
+
+// Exact reference distance (hnswalg.cpp:326-357) of one row evaluated by a QUAD of lanes: lane t of the quad
+// owns accumulators 2t and 2t+1 of the reference's eight, i.e. dims 8j+2t, 8j+2t+1 for j = 0..d/8-1 in
+// increasing order -- exactly the order each __m256 lane accumulates in.  All d/8 8-byte loads of a lane are
+// independent (one round trip per row); the quad then sums the eight accumulators left to right.
+// Every lane of the quad returns the distance.
+__device__ __forceinline__ float l2_ref_order_quad(const float *__restrict__ row, const float *sq, int d, int t)
+{
+    const float2 *r2 = reinterpret_cast<const float2 *>(row) + t;
+    const float2 *q2 = reinterpret_cast<const float2 *>(sq) + t;
+    float alo = 0.f, ahi = 0.f;
+    const int nj = d >> 3;
+#pragma unroll 16
+    for (int j = 0; j < nj; j++) {
+        const float2 y = r2[4 * j];
+        const float2 x = q2[4 * j];
+        const float d0 = __fsub_rn(x.x, y.x), d1 = __fsub_rn(x.y, y.y);
+        alo = __fadd_rn(alo, __fmul_rn(d0, d0));
+        ahi = __fadd_rn(ahi, __fmul_rn(d1, d1));
+    }
+    float r = __fadd_rn(quad_bcast<0>(alo), quad_bcast<0>(ahi));
+    r = __fadd_rn(r, quad_bcast<1>(alo));
+    r = __fadd_rn(r, quad_bcast<1>(ahi));
+    r = __fadd_rn(r, quad_bcast<2>(alo));
+    r = __fadd_rn(r, quad_bcast<2>(ahi));
+    r = __fadd_rn(r, quad_bcast<3>(alo));
+    r = __fadd_rn(r, quad_bcast<3>(ahi));
+    return r;
 }
 
 template <int NCH> struct RSet {
@@ -177,7 +229,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         int ntail = 0; // evicted entries whose distance still equals the lower bound
         {
             // hnswalg.cpp:56-62: seed with the enter point
-            const float d0 = l2_ref_order(g.vectors + (size_t)g.enterpoint * g.d, s_q, g.d);
+            const float d0 = l2_ref_order_quad(g.vectors + (size_t)g.enterpoint * g.d, s_q, g.d, lane & 3);
             if (lane == 0) {
                 R.r[0] = mk_key(d0, g.enterpoint);
                 atomicOr(&bm[g.enterpoint >> 5], 1u << (g.enterpoint & 31));
@@ -233,49 +285,61 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             if (lane < g.maxM)
                 nb = g.links[(size_t)node * g.maxM + lane]; // issued together with the count
             bool fresh = false;
-            float dist = 0.f;
             if (lane < cnt) {
                 const uint32_t bit = 1u << (nb & 31);
                 const uint32_t old = atomicOr(&bm[nb >> 5], bit);
                 fresh = !(old & bit);
             }
-            if (fresh)
-                dist = l2_ref_order(g.vectors + (size_t)nb * g.d, s_q, g.d);
-            unsigned long long todo = __ballot(fresh);
+            const unsigned long long mask = __ballot(fresh);
+            const int nfresh = __popcll(mask);
 
-            // ---- admissions in link order (hnswalg.cpp:93-103)
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dist), j));
-                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nb, j);
-                const unsigned long long topk = R.get(n - 1);
-                const float topd = __uint_as_float(key_dist_bits(topk));
-                if (!(topd > dj || n < ef))
-                    continue;
-                const unsigned long long K = mk_key(dj, idj);
-                const int pos = R.rank_of(K, n, lane);
-                const bool full = n == ef;
-                R.insert_at(K, pos, lane);
-                if (!full)
-                    n++;
-                // bookkeeping of candidates that left topResults but may still be popped
-                const uint32_t newmax = key_dist_bits(R.get(n - 1));
-                if (ntail > 0 && key_dist_bits(tail[0]) != newmax)
-                    ntail = 0; // lower bound moved below them: dead for good
-                if (full && !(topk & 1ull) && key_dist_bits(topk) == newmax) {
-                    if (ntail < kTailCap) {
-                        __syncthreads();
-                        if (lane == 0)
-                            tail[ntail] = topk;
-                        ntail++;
-                        __syncthreads();
-                    } else {
-                        // more than kTailCap exact distance ties at the boundary: cannot be represented
-                        if (lane == 0)
-                            atomicOr(status, kStatusHnswTieOverflow);
-                        ntail = -1;
-                        break;
+            // ---- distances, 16 rows per pass (a quad of lanes per row), then admissions in link order
+            for (int base = 0; base < nfresh && ntail >= 0; base += 16) {
+                const int r = base + (lane >> 2);
+                const bool active = r < nfresh;
+                const int src = active ? nth_set_bit(mask, r) : 0;
+                const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
+                float dq = 0.f;
+                if (active)
+                    dq = l2_ref_order_quad(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 3);
+                // Rows that cannot be admitted are dropped wave-wide before the sequential part: once the
+                // set is full its maximum only decreases, so a row failing 'top > dist' (hnswalg.cpp:93)
+                // against the current maximum fails against every later one too.
+                const float top0 = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                unsigned long long cand = __ballot(active && (lane & 3) == 0 && (n < ef || top0 > dq));
+                while (cand) { // hnswalg.cpp:93-103, in link order
+                    const int b = __ffsll((long long)cand) - 1;
+                    cand &= cand - 1;
+                    const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b));
+                    const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nbq, b);
+                    const unsigned long long topk = R.get(n - 1);
+                    const float topd = __uint_as_float(key_dist_bits(topk));
+                    if (!(topd > dj || n < ef))
+                        continue;
+                    const unsigned long long K = mk_key(dj, idj);
+                    const int pos = R.rank_of(K, n, lane);
+                    const bool full = n == ef;
+                    R.insert_at(K, pos, lane);
+                    if (!full)
+                        n++;
+                    // bookkeeping of candidates that left topResults but may still be popped
+                    const uint32_t newmax = key_dist_bits(R.get(n - 1));
+                    if (ntail > 0 && key_dist_bits(tail[0]) != newmax)
+                        ntail = 0; // lower bound moved below them: dead for good
+                    if (full && !(topk & 1ull) && key_dist_bits(topk) == newmax) {
+                        if (ntail < kTailCap) {
+                            __syncthreads();
+                            if (lane == 0)
+                                tail[ntail] = topk;
+                            ntail++;
+                            __syncthreads();
+                        } else {
+                            // more than kTailCap exact distance ties at the boundary: cannot be represented
+                            if (lane == 0)
+                                atomicOr(status, kStatusHnswTieOverflow);
+                            ntail = -1;
+                            break;
+                        }
                     }
                 }
             }
@@ -300,7 +364,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 int coarse_slots_for(int ef)
 {
     const int nch = (ef + 63) / 64;
-    const int waves_per_simd = nch <= 4 ? 8 : (nch <= 8 ? 5 : 3);
+    const int waves_per_simd = nch <= 8 ? 4 : 3;
     return 256 * 4 * waves_per_simd;
 }
 
@@ -320,10 +384,12 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
 #define IVFHNSW_WALK(N, W)                                                                                          \
     hipLaunchKernelGGL((hnsw_walk_kernel<N, W>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef, coarse_ids, \
                        coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
-    // tuning knob (A/B on the device): 8 waves/SIMD with a few spilled registers vs 5 without
+    // tuning knob (A/B on the device).  Measured on MI355X (100M / 2^17-centroid workload, ef 80): the
+    // walk is bound by per-wave instruction issue, and 4 waves/SIMD with ~110 VGPRs (2.05 ms per 10 k
+    // queries) beats 8 waves/SIMD with ~55 (2.6 ms), so 4 is the default.
     static const bool occ8 = [] {
         const char *e = getenv("IVFHNSW_WALK_OCC");
-        return !(e && atoi(e) < 8);
+        return e && atoi(e) >= 8;
     }();
     if (nch <= 1) {
         if (occ8) IVFHNSW_WALK(1, 8); else IVFHNSW_WALK(1, 4);

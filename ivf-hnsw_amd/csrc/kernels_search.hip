@@ -8,6 +8,7 @@
 #include "device_common.h"
 
 #include <float.h>
+#include <stdlib.h>
 #include <algorithm>
 
 namespace ivfhnsw_gpu_impl {
@@ -206,20 +207,49 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
-template <int CS, int SEGCAP, int U>
-__global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict__ codes,
-                                                      const uint8_t *__restrict__ norm_codes,
-                                                      const float *__restrict__ luts,
-                                                      const float *__restrict__ norm_table,
-                                                      const Seg *__restrict__ segs, const uint32_t *__restrict__ lpos,
-                                                      const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                      unsigned long long *__restrict__ keys)
+// LDS bank replication (REP > 1): with one copy of the table the 32 lanes of a half-wave gather from 32
+// banks at random (expected worst bank ~3.5 deep per ds_read_b32).  With REP copies, copy r lives only in
+// banks [r*32/REP, (r+1)*32/REP) and lane l uses copy (l % 32) / (32/REP), so 32/REP lanes share 32/REP
+// banks (expected worst bank ~2.4 deep at REP = 4): entry e of copy r of sub-table m is the dword
+// m*256*REP + (e / G)*32 + r*G + e % G with G = 32/REP.
+template <int REP> __device__ __forceinline__ uint32_t lut_byte_offset(uint32_t e, uint32_t rbase)
 {
-    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
+    if constexpr (REP == 1)
+        return e << 2;
+    else if constexpr (REP == 2)
+        return ((e & 0xF0u) << 3) | ((e & 15u) << 2) | rbase;
+    else
+        return ((e & 0xF8u) << 4) | ((e & 7u) << 2) | rbase;
+}
+
+template <int CS, int REP>
+__device__ __forceinline__ float adc_sum_rep(const float *s_lut, const uint32_t (&w)[CS / 4], uint32_t rbase)
+{
+    float sum = 0.0f;
+    const char *base = reinterpret_cast<const char *>(s_lut);
+#pragma unroll
+    for (int m = 0; m < CS; m++) {
+        const uint32_t e = (w[m >> 2] >> ((m & 3) * 8)) & 0xffu;
+        sum = __fadd_rn(sum, *reinterpret_cast<const float *>(base + m * 1024 * REP + lut_byte_offset<REP>(e, rbase)));
+    }
+    return sum;
+}
+
+template <int CS, int SEGCAP, int U, int REP, int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restrict__ codes,
+                                                          const uint8_t *__restrict__ norm_codes,
+                                                          const float *__restrict__ luts,
+                                                          const float *__restrict__ norm_table,
+                                                          const Seg *__restrict__ segs,
+                                                          const uint32_t *__restrict__ lpos,
+                                                          const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
+                                                          unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256 * REP];
     __shared__ float s_norm[256];
     __shared__ __attribute__((aligned(16))) Seg s_seg[SEGCAP];
     __shared__ uint32_t s_lpos[SEGCAP + 1];
-    __shared__ unsigned long long s_red[4];
+    __shared__ unsigned long long s_red[THREADS / 64];
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x / nsplit;
@@ -229,7 +259,7 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
         return;
     // this split's slice of the virtual code array, in multiples of the block width
     uint32_t per = (h.total + nsplit - 1) / nsplit;
-    per = (per + 255u) & ~255u;
+    per = (per + (THREADS - 1)) & ~(uint32_t)(THREADS - 1);
     const uint32_t lo = min((uint32_t)split * per, h.total);
     const uint32_t hi = min(lo + per, h.total);
     if (lo >= hi)
@@ -237,12 +267,31 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
 
     {
         const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
-        float4 *dst = reinterpret_cast<float4 *>(s_lut);
+        if constexpr (REP == 1) {
+            float4 *dst = reinterpret_cast<float4 *>(s_lut);
+            for (int i = tid; i < CS * 64; i += THREADS)
+                dst[i] = src[i];
+        } else {
+            constexpr int G = 32 / REP; // dwords of one copy inside a 32-dword bank row
+            char *base = reinterpret_cast<char *>(s_lut);
+            for (int i = tid; i < CS * 64; i += THREADS) {
+                const float4 v = src[i];
+                const int m = i >> 6, e = (i & 63) * 4; // entries e..e+3 of sub-table m
+                char *row = base + m * 1024 * REP + (e / G) * 128 + (e % G) * 4;
+                // copy order rotated per lane so that the 8 lanes a ds_write_b128 services together cover
+                // the 8 distinct 16-byte slots of a 128-byte bank row (conflict-free)
+                const int r0 = (i / (G / 4)) % REP;
 #pragma unroll
-        for (int i = 0; i < CS * 64 / 256; i++)
-            dst[i * 256 + tid] = src[i * 256 + tid];
-        s_norm[tid] = norm_table[tid];
+                for (int j = 0; j < REP; j++) {
+                    const int r = (r0 + j) % REP;
+                    *reinterpret_cast<float4 *>(row + r * G * 4) = v;
+                }
+            }
+        }
+        for (int i = tid; i < 256; i += THREADS)
+            s_norm[i] = norm_table[i];
     }
+    const uint32_t rbase = REP == 1 ? 0u : (uint32_t)(((tid & 31) / (32 / REP)) * (32 / REP) * 4);
 
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t *lq = lpos + (size_t)q * max_seg;
@@ -251,7 +300,7 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
     for (uint32_t cs = 0; cs < h.nseg; cs += SEGCAP) {
         const uint32_t cn = min((uint32_t)SEGCAP, h.nseg - cs);
         __syncthreads(); // previous chunk fully consumed (and LUT staged, first time)
-        for (uint32_t i = tid; i < cn; i += 256) {
+        for (uint32_t i = tid; i < cn; i += THREADS) {
             s_seg[i] = sq[cs + i];
             s_lpos[i] = lq[cs + i];
         }
@@ -262,14 +311,14 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
         const uint32_t cl = s_lpos[0];
         const uint32_t b0 = max(cl, lo), b1 = min(ch, hi);
         uint32_t s = 0;
-        for (uint32_t base = b0; base < b1; base += 256 * U) {
+        for (uint32_t base = b0; base < b1; base += THREADS * U) {
             uint32_t w[U][CS / 4];
             uint32_t nb[U], vp[U];
             float ct[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const uint32_t p = base + u * 256 + tid;
+                const uint32_t p = base + u * THREADS + tid;
                 ok[u] = p < b1;
                 if (ok[u]) {
                     if constexpr (SEGCAP <= 64) {
@@ -299,7 +348,7 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (ok[u]) {
-                    const float sum = adc_sum<CS>(s_lut, w[u]);
+                    const float sum = adc_sum_rep<CS, REP>(s_lut, w[u], rbase);
                     const float tt = __fadd_rn(ct[u], s_norm[nb[u]]);
                     const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
                     if (dist < FLT_MAX) { // also rejects NaN, as 'dist < distances[0]' does
@@ -318,9 +367,9 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
     __syncthreads();
     if (tid == 0) {
         unsigned long long b = s_red[0];
-        b = s_red[1] < b ? s_red[1] : b;
-        b = s_red[2] < b ? s_red[2] : b;
-        b = s_red[3] < b ? s_red[3] : b;
+#pragma unroll
+        for (int i = 1; i < THREADS / 64; i++)
+            b = s_red[i] < b ? s_red[i] : b;
         if (nsplit == 1)
             keys[q] = b;
         else if (b < kKeyInit)
@@ -328,19 +377,39 @@ __global__ __launch_bounds__(256) void scan_k1_kernel(const uint8_t *__restrict_
     }
 }
 
+// tuning knob for A/B runs on the device: IVFHNSW_SCAN_REP = 1, 2 or 4 (LDS copies of the table)
+static int scan_rep_choice()
+{
+    static const int rep = [] {
+        const char *e = getenv("IVFHNSW_SCAN_REP");
+        const int v = e ? atoi(e) : 1;
+        return (v == 2 || v == 4) ? v : 1;
+    }();
+    return rep;
+}
+
 template <int CS>
 static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
                                  const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
                                  uint64_t *keys)
 {
-    dim3 grid((unsigned)nq * nsplit), block(256);
+    dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
-    if (max_seg <= 64)
-        hipLaunchKernelGGL((scan_k1_kernel<CS, 64, 4>), grid, block, 0, s, t.codes, t.norm_codes, luts, t.norm_table,
-                           segs, lpos, hdr, max_seg, nsplit, k64);
-    else
-        hipLaunchKernelGGL((scan_k1_kernel<CS, 1024, 4>), grid, block, 0, s, t.codes, t.norm_codes, luts,
-                           t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64);
+#define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                                                                          \
+    hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, 4, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
+                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64)
+    const int rep = CS <= 16 ? scan_rep_choice() : 1;
+    if (max_seg <= 64) {
+        if (rep == 4)
+            IVFHNSW_SCAN(64, 4, 512);
+        else if (rep == 2)
+            IVFHNSW_SCAN(64, 2, 256);
+        else
+            IVFHNSW_SCAN(64, 1, 256);
+    } else {
+        IVFHNSW_SCAN(1024, 1, 256);
+    }
+#undef IVFHNSW_SCAN
     return hipGetLastError();
 }
 
