@@ -50,8 +50,6 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-coarse", action="store_true",
-                    help="feed the oracle's coarse stage instead of running the HNSW walk on the device (debug)")
     args = ap.parse_args()
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # oracle threads must not spin inside a CPU quota
@@ -62,6 +60,8 @@ def main():
     import synth
 
     pkg = ge.load_pkg()
+    import importlib
+    pkg_dist = importlib.import_module("ivfhnsw_amd.distributed")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,36 +105,15 @@ def main():
     d_q = torch.from_numpy(queries).to(dev)
     d_dist = torch.empty((nq, 1), dtype=torch.float32, device=dev)
     d_lab = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-    d_keys = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-    d_cid = torch.empty((nq, nprobe), dtype=torch.int32, device=dev)
-    d_cd = torch.empty((nq, nprobe), dtype=torch.float32, device=dev)
-
-    host_coarse = None
-    if args.host_coarse:
-        raise SystemExit("--host-coarse needs the oracle corpus; use the tests instead")
-
-    # query slices for the sharded coarse stage
-    per = (nq + world - 1) // world
-    q_lo, q_hi = min(rank * per, nq), min((rank + 1) * per, nq)
-    if world > 1:
-        d_cid_pad = torch.empty((per * world, nprobe), dtype=torch.int32, device=dev)
-        d_cd_pad = torch.empty((per * world, nprobe), dtype=torch.float32, device=dev)
+    sharded = pkg_dist.ShardedSearcher(g, rank, world, nq, nprobe, dev) if world > 1 else None
 
     def step():
         if world == 1:
             g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, efSearch=ef)
-            return
-        # 1. coarse walk for this rank's slice of the batch, 2. all-gather, 3. scan own shard for all queries,
-        # 4. MIN over shards of the packed keys, 5. owner resolves labels, MAX over shards
-        if q_hi > q_lo:
-            g.coarse_dev(q_hi - q_lo, d_q[q_lo:q_hi], nprobe, ef, d_cid_pad[rank * per:], d_cd_pad[rank * per:])
-        dist.all_gather_into_tensor(d_cid_pad, d_cid_pad[rank * per:(rank + 1) * per])
-        dist.all_gather_into_tensor(d_cd_pad, d_cd_pad[rank * per:(rank + 1) * per])
-        g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, d_coarse_ids=d_cid_pad, d_coarse_dists=d_cd_pad,
-                     d_out_keys=d_keys)
-        dist.all_reduce(d_keys, op=dist.ReduceOp.MIN)
-        g.resolve_keys_dev(nq, 1, d_keys, d_dist, d_lab)
-        dist.all_reduce(d_lab, op=dist.ReduceOp.MAX)
+        else:
+            # coarse walk for this rank's slice of the batch -> all-gather -> scan own shard for all queries ->
+            # MIN over shards of the packed keys -> owner resolves labels -> MAX over shards
+            sharded.step(d_q, d_dist, d_lab, max_codes, ef)
 
     def barrier():
         torch.cuda.synchronize()

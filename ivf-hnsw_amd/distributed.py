@@ -1,0 +1,85 @@
+"""Multi-GPU search: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+SURVEY.md 8e: every rank holds the replicated tables (graph, centroid norms, code books, list offsets);
+the inverted lists are sharded list-wise (list c lives on rank c % world).  The scan plan (probe order,
+max_codes rule, pruning) is derived identically on every rank from the replicated tables, each rank
+scores only the lists it owns, and ONE tiny exchange per query batch merges the per-shard winners:
+
+    keys   : int64 MIN all-reduce of the packed (orderable distance << 32 | scan position) keys -- the scan
+             position reproduces the reference's strict-'<' first-scanned-wins rule (IndexIVF_HNSW.cpp:285)
+             across shards;
+    labels : the owner of the winning scan position resolves the label, the others contribute -1, MAX
+             all-reduce.
+
+The coarse HNSW walk is split over the ranks by query and all-gathered, so no stage is replicated work.
+Payload per 10 k-query batch: 2 x 80 KB (keys, labels) + 2.5 MB (coarse stage): latency-bound, one
+collective each, never per query.
+"""
+import numpy as np
+
+SIGN_FLIP = np.uint64(0x8000000000000000)
+KEY_INIT = (np.uint64(0x7f7fffff | 0x80000000) << np.uint64(32))
+
+
+def pack_keys(dist, vpos):
+    """numpy mirror of the device key (device_common.h f32_orderable + kernels_search.hip scan): the signed
+    int64 whose order is (distance, scan position).  Used by the CPU tests of the merge protocol."""
+    d = np.ascontiguousarray(dist, np.float32) + np.float32(0.0)
+    u = d.view(np.uint32).astype(np.uint64)
+    neg = (u & np.uint64(0x80000000)) != 0
+    o = np.where(neg, (~u) & np.uint64(0xffffffff), u | np.uint64(0x80000000))
+    key = (o << np.uint64(32)) | np.ascontiguousarray(vpos, np.uint32).astype(np.uint64)
+    return (key ^ SIGN_FLIP).view(np.int64)
+
+
+def unpack_keys(skey):
+    key = np.ascontiguousarray(skey, np.int64).view(np.uint64) ^ SIGN_FLIP
+    o = (key >> np.uint64(32)).astype(np.uint32)
+    vpos = (key & np.uint64(0xffffffff)).astype(np.uint32)
+    u = np.where((o & np.uint32(0x80000000)) != 0, o & np.uint32(0x7fffffff), ~o)
+    return u.astype(np.uint32).view(np.float32), vpos
+
+
+def query_slice(nq, rank, world):
+    """(lo, hi, per): the queries whose coarse stage `rank` computes; `per` rows per rank in the padded
+    all-gather buffer."""
+    per = (nq + world - 1) // world
+    return min(rank * per, nq), min((rank + 1) * per, nq), per
+
+
+def merge_keys_labels(keys, labels_of_owner, group=None):
+    """The exchange step on tensors of any device: in-place MIN of the signed keys; returns nothing.
+    `labels_of_owner` must already hold -1 wherever this rank does not own the (pre-merge) winner; it is
+    MAX-reduced after the caller re-resolved it against the merged keys."""
+    import torch.distributed as dist
+    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+
+
+class ShardedSearcher:
+    """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller."""
+
+    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None):
+        import torch
+        self.g, self.rank, self.world, self.nq, self.nprobe, self.group = gpu_index, rank, world, nq, nprobe, group
+        self.lo, self.hi, self.per = query_slice(nq, rank, world)
+        self.cid = torch.empty((self.per * world, nprobe), dtype=torch.int32, device=device)
+        self.cd = torch.empty((self.per * world, nprobe), dtype=torch.float32, device=device)
+        self.keys = torch.empty((nq, 1), dtype=torch.int64, device=device)
+
+    def step(self, d_q, d_dist, d_lab, max_codes, efSearch, do_pruning=False):
+        """One batch: coarse slice -> all-gather -> scan own shard -> MIN keys -> resolve -> MAX labels.
+        (OPQ: d_q must already be rotated for the coarse slice; the bench workload has no OPQ.)"""
+        import torch.distributed as dist
+        g, r, per = self.g, self.rank, self.per
+        if self.hi > self.lo:
+            g.coarse_dev(self.hi - self.lo, d_q[self.lo:self.hi], self.nprobe, efSearch,
+                         self.cid[r * per:], self.cd[r * per:])
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.cid, self.cid[r * per:(r + 1) * per], group=self.group)
+            dist.all_gather_into_tensor(self.cd, self.cd[r * per:(r + 1) * per], group=self.group)
+        g.search_dev(self.nq, 1, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
+                     d_coarse_dists=self.cd, do_pruning=do_pruning, d_out_keys=self.keys)
+        if self.world > 1:
+            dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)
+            g.resolve_keys_dev(self.nq, 1, self.keys, d_dist, d_lab)
+            dist.all_reduce(d_lab, op=dist.ReduceOp.MAX, group=self.group)

@@ -1,0 +1,135 @@
+"""CPU test of the multi-GPU exchange step with real torch.distributed ranks (gloo, world 2/3).
+
+Each rank emulates its shard in numpy (the scan plan of IndexIVF_HNSW.cpp:267-292 with global scan positions,
+ADC in the oracle's float order, only lists c % world == rank), then the ranks run exactly the collectives the
+GPU path runs (ivf-hnsw_amd/distributed.py): int64 MIN all-reduce of the packed keys, MAX all-reduce of the
+owner's labels.  The merged result must equal the unsharded oracle bit for bit -- including which of several
+equal distances wins (first scanned).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _shard_best(c, q, cid, cd, max_codes, rank, world, pack_keys):
+    """Best (key, label) over the lists owned by `rank`, numpy restatement of plan + scan."""
+    from oracle import orc
+    F = np.float32
+    off = c["offsets"].astype(np.int64)
+    M = c["code_size"]
+    nq = len(q)
+    keys = np.empty(nq, np.int64)
+    labels = np.full(nq, -1, np.int64)
+    for i in range(nq):
+        tab = orc.inner_prod_table(q[i], c["pq_centroids"], M)
+        ncode = 0
+        best_d, best_v, best_l = None, None, -1
+        for p, cc in enumerate(cid[i]):
+            cc = int(cc)
+            n = off[cc + 1] - off[cc]
+            if n == 0:
+                continue
+            if cc % world == rank:
+                codes = c["codes"][off[cc]:off[cc + 1]]
+                s = np.zeros(n, F)
+                for m in range(M):
+                    s = (s + tab[m, codes[:, m]]).astype(F)
+                term1 = F(cd[i, p] - c["centroid_norms"][cc])
+                dist = ((term1 + c["norm_table"][c["norm_codes"][off[cc]:off[cc + 1]]]).astype(F) - F(2) * s).astype(F)
+                j = int(np.argmin(dist))  # first minimum = first scanned
+                if best_d is None or dist[j] < best_d:
+                    best_d, best_v, best_l = dist[j], ncode + j, int(c["ids"][off[cc] + j])
+            ncode += n
+            if ncode >= max_codes:
+                break
+        if best_d is None:
+            keys[i] = pack_keys(np.array([np.finfo(F).max], F), np.array([0], np.uint32))[0]
+        else:
+            keys[i] = pack_keys(np.array([best_d], F), np.array([best_v], np.uint32))[0]
+            labels[i] = best_l
+    return keys, labels
+
+
+def _worker(rank, world, port, ties, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import importlib
+    import synth
+    ge.load_pkg()
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = synth.make_corpus(seed=51, nc=96, d=64, M=8, n_base=6000, nq=24, efConstruction=60)
+    if ties:  # every code identical: all distances inside a list tie, across lists they differ by term1
+        c["codes"] = np.zeros_like(c["codes"])
+        c["norm_codes"] = np.zeros_like(c["norm_codes"])
+    nprobe, max_codes, ef = 12, 700, 32
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef)
+    ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=1)
+
+    # the coarse stage is split over the ranks by query and all-gathered, as on the GPUs
+    lo, hi, per = D.query_slice(len(cid), rank, world)
+    cid_pad = torch.zeros((per * world, nprobe), dtype=torch.int32)
+    cd_pad = torch.zeros((per * world, nprobe), dtype=torch.float32)
+    cid_pad[rank * per:rank * per + (hi - lo)] = torch.from_numpy(cid[lo:hi].astype(np.int32))
+    cd_pad[rank * per:rank * per + (hi - lo)] = torch.from_numpy(cd[lo:hi])
+    dist.all_gather_into_tensor(cid_pad, cid_pad[rank * per:(rank + 1) * per].clone())
+    dist.all_gather_into_tensor(cd_pad, cd_pad[rank * per:(rank + 1) * per].clone())
+    g_cid = cid_pad.numpy()[:len(cid)].astype(np.uint32)
+    g_cd = cd_pad.numpy()[:len(cid)]
+    assert np.array_equal(g_cid, cid) and np.array_equal(g_cd, cd)
+
+    keys, labels = _shard_best(c, c["queries"], g_cid, g_cd, max_codes, rank, world, D.pack_keys)
+    tk = torch.from_numpy(keys.copy())
+    dist.all_reduce(tk, op=dist.ReduceOp.MIN)
+    merged = tk.numpy()
+    mine = merged == keys
+    tl = torch.from_numpy(np.where(mine, labels, -1))
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+    dd, vv = D.unpack_keys(merged)
+    ok = np.array_equal(tl.numpy(), ref_l[:, 0]) and np.array_equal(dd.view(np.uint32), ref_d[:, 0].view(np.uint32))
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "fail")), "w").write(
+        "%s\n%s\n" % (tl.numpy().tolist(), ref_l[:, 0].tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ties", [(2, False), (2, True), (3, False)])
+def test_shard_merge_equals_unsharded_oracle(tmp_path, world, ties):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000) + world * 7 + (1 if ties else 0)
+    mp.spawn(_worker, args=(world, port, ties, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("rank%d.ok" % r)), open(tmp_path / ("rank%d.fail" % r)).read()
+
+
+def test_key_packing_orders_like_distance_then_position():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    import importlib
+    ge.load_pkg()
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    rng = np.random.default_rng(0)
+    d = rng.normal(0, 1e4, 2000).astype(np.float32)
+    d[:50] = d[50:100]                      # exact ties
+    d[100] = 0.0
+    d[101] = -0.0
+    v = rng.permutation(2000).astype(np.uint32)
+    k = D.pack_keys(d, v)
+    order = np.argsort(k, kind="stable")
+    want = np.lexsort((v, d + np.float32(0)))
+    assert np.array_equal(order, want)
+    dd, vv = D.unpack_keys(k)
+    assert np.array_equal(vv, v) and np.array_equal(dd, d + np.float32(0))
+    # FLT_MAX / "nothing found" sorts after every finite distance
+    init = D.pack_keys(np.array([np.finfo(np.float32).max], np.float32), np.array([0], np.uint32))[0]
+    assert (k < init).all()
