@@ -56,6 +56,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s not built: run __graft_entry__.build() (make -C ivf-hnsw_amd/csrc)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; one process must not initialise two HIP runtimes
+        # (torch then reports "No HIP GPUs are available").  Loading torch first makes this library bind to
+        # the runtime torch uses, whichever of the two the caller touches first afterwards.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.ivfhnsw_gpu_last_error.restype = C.c_char_p
         L.ivfhnsw_gpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
