@@ -202,7 +202,7 @@ int check_desc(const ivfhnsw_ivf_desc *d, bool need_lists)
         return fail(IVFHNSW_ERR_INVALID, "nc too large");
     if (!d->offsets || !d->centroid_norms || !d->pq_centroids || !d->norm_table)
         return fail(IVFHNSW_ERR_INVALID, "offsets, centroid_norms, pq_centroids and norm_table are required");
-    if (need_lists && (!d->ids || !d->codes || !d->norm_codes))
+    if (need_lists && d->offsets[d->nc] != 0 && (!d->ids || !d->codes || !d->norm_codes))
         return fail(IVFHNSW_ERR_INVALID, "ids, codes and norm_codes are required");
     if (d->shard_world == 0 || d->shard_rank >= d->shard_world)
         return fail(IVFHNSW_ERR_INVALID, "bad shard %u of %u", d->shard_rank, d->shard_world);

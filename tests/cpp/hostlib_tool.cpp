@@ -1,0 +1,151 @@
+// Test driver for the host-side class surface (include/ivf-hnsw/*.h, libivfhnsw.so).  Sub-commands are
+// exercised by tests/test_host_library.py; the file-format ones need no GPU.
+//
+//   index_roundtrip ivf|grouping d nc code_size nsubc in.index out.index
+//   hnsw_roundtrip info data edges out_info out_edges
+//   hnsw_build data.fvecs n d M efConstruction out_info out_edges
+//   hnsw_search info data edges queries.fvecs nq ef k out.bin        (host walk: ids u32[nq*k], dists f32[nq*k])
+//   pq_roundtrip in out | vt_roundtrip in out
+//   search ivf|grouping d nc code_size nsubc centroids info edges pq norm_pq opq|- index queries.fvecs nq k nprobe
+//          max_codes efSearch pruning out.bin                        (GPU; single-query loop AND batch)
+#include <ivf-hnsw/IndexIVF_HNSW_Grouping.h>
+#include <ivf-hnsw/hnswalg.h>
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+using namespace ivfhnsw;
+
+static void dump(const char *path, const void *a, size_t na, const void *b, size_t nb)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f || fwrite(a, 1, na, f) != na || fwrite(b, 1, nb, f) != nb)
+        throw std::runtime_error(std::string("cannot write ") + path);
+    fclose(f);
+}
+
+static int run(int argc, char **argv)
+{
+    const std::string cmd = argc > 1 ? argv[1] : "";
+    if (cmd == "index_roundtrip" && argc == 9) {
+        const bool grp = !strcmp(argv[2], "grouping");
+        const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);
+        if (grp) {
+            IndexIVF_HNSW_Grouping ix(d, nc, cs, 8, nsubc);
+            ix.read(argv[7]);
+            ix.write(argv[8]);
+        } else {
+            IndexIVF_HNSW ix(d, nc, cs, 8);
+            ix.read(argv[7]);
+            ix.write(argv[8]);
+        }
+        return 0;
+    }
+    if (cmd == "hnsw_roundtrip" && argc == 7) {
+        hnswlib::HierarchicalNSW g(argv[2], argv[3], argv[4]);
+        g.SaveInfo(argv[5]);
+        g.SaveEdges(argv[6]);
+        return 0;
+    }
+    if (cmd == "hnsw_build" && argc == 9) {
+        const size_t n = atol(argv[3]), d = atol(argv[4]), M = atol(argv[5]), efc = atol(argv[6]);
+        hnswlib::HierarchicalNSW g(d, n, M, 2 * M, efc);
+        std::ifstream in(argv[2], std::ios::binary);
+        std::vector<float> v(d);
+        for (size_t i = 0; i < n; i++) {
+            readXvec<float>(in, v.data(), d);
+            g.addPoint(v.data());
+        }
+        g.SaveInfo(argv[7]);
+        g.SaveEdges(argv[8]);
+        return 0;
+    }
+    if (cmd == "hnsw_search" && argc == 10) {
+        hnswlib::HierarchicalNSW g(argv[2], argv[3], argv[4]);
+        const size_t nq = atol(argv[6]), ef = atol(argv[7]), k = atol(argv[8]);
+        g.efSearch = ef;
+        std::vector<float> q(nq * g.d_);
+        std::ifstream in(argv[5], std::ios::binary);
+        readXvec<float>(in, q.data(), g.d_, nq);
+        std::vector<uint32_t> ids(nq * k, 0xffffffffu);
+        std::vector<float> dist(nq * k, 0.f);
+        for (size_t i = 0; i < nq; i++) {
+            auto res = g.searchKnn(q.data() + i * g.d_, k);
+            for (size_t j = res.size(); j-- > 0;) {
+                ids[i * k + j] = res.top().second;
+                dist[i * k + j] = res.top().first;
+                res.pop();
+            }
+        }
+        dump(argv[9], ids.data(), ids.size() * 4, dist.data(), dist.size() * 4);
+        return 0;
+    }
+    if (cmd == "pq_roundtrip" && argc == 4) {
+        faiss::ProductQuantizer *pq = faiss::read_ProductQuantizer(argv[2]);
+        faiss::write_ProductQuantizer(pq, argv[3]);
+        delete pq;
+        return 0;
+    }
+    if (cmd == "vt_roundtrip" && argc == 4) {
+        faiss::VectorTransform *vt = faiss::read_VectorTransform(argv[2]);
+        faiss::write_VectorTransform(vt, argv[3]);
+        delete vt;
+        return 0;
+    }
+    if (cmd == "search" && argc == 22) {
+        const bool grp = !strcmp(argv[2], "grouping");
+        const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);
+        const char *centroids = argv[7], *info = argv[8], *edges = argv[9], *ppq = argv[10], *pnorm = argv[11],
+                   *popq = argv[12], *pindex = argv[13], *pq_ = argv[14];
+        const size_t nq = atol(argv[15]), k = atol(argv[16]), nprobe = atol(argv[17]), max_codes = atol(argv[18]),
+                     ef = atol(argv[19]);
+        const bool pruning = atoi(argv[20]) != 0;
+        // the load sequence of the reference's drivers (tests/test_ivfhnsw_sift1b.cpp:47-67,125-129,164-183)
+        IndexIVF_HNSW_Grouping *gix = grp ? new IndexIVF_HNSW_Grouping(d, nc, cs, 8, nsubc) : nullptr;
+        IndexIVF_HNSW *index = grp ? gix : new IndexIVF_HNSW(d, nc, cs, 8);
+        index->build_quantizer(centroids, info, edges, 16, 500);
+        index->do_opq = strcmp(popq, "-") != 0;
+        delete index->pq;
+        index->pq = faiss::read_ProductQuantizer(ppq);
+        if (index->do_opq)
+            index->opq_matrix = dynamic_cast<faiss::LinearTransform *>(faiss::read_VectorTransform(popq));
+        delete index->norm_pq;
+        index->norm_pq = faiss::read_ProductQuantizer(pnorm);
+        index->read(pindex);
+        if (index->do_opq)
+            index->rotate_quantizer();
+        index->nprobe = nprobe;
+        index->max_codes = max_codes;
+        index->quantizer->efSearch = ef;
+        if (gix)
+            gix->do_pruning = pruning;
+        std::vector<float> q(nq * d);
+        {
+            std::ifstream in(pq_, std::ios::binary);
+            readXvec<float>(in, q.data(), d, nq);
+        }
+        // (1) one query per call, as the drivers do; (2) the batched extension.  Both are written out.
+        std::vector<float> dist(2 * nq * k);
+        std::vector<long> lab(2 * nq * k);
+        for (size_t i = 0; i < nq; i++)
+            index->search(k, q.data() + i * d, dist.data() + i * k, lab.data() + i * k);
+        index->search_batch(nq, k, q.data(), dist.data() + nq * k, lab.data() + nq * k);
+        dump(argv[21], lab.data(), lab.size() * sizeof(long), dist.data(), dist.size() * sizeof(float));
+        delete index;
+        return 0;
+    }
+    fprintf(stderr, "usage: see the header of tests/cpp/hostlib_tool.cpp (got %d args for '%s')\n", argc, cmd.c_str());
+    return 2;
+}
+
+int main(int argc, char **argv)
+{
+    try {
+        return run(argc, argv);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hostlib_tool: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,194 @@
+"""The host-side class surface (include/ivf-hnsw/*.h + libivfhnsw.so): file formats against the oracle's
+independent reader/writer (CPU), host graph construction/walk against the oracle (CPU), search()/search_batch()
+through the classes against the oracle (GPU), and -- when the reference tree is present at build time -- the
+reference's OWN driver binary, built unchanged against these headers, run end to end (GPU)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hostio
+import synth
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tests", "cpp", "hostlib_tool.bin")
+REF_DRV = os.path.join(ROOT, "oracle", "_ref")
+
+
+def tool(*args):
+    assert os.path.exists(TOOL), "run __graft_entry__.build()"
+    r = subprocess.run([TOOL] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+def small(**kw):
+    base = dict(seed=61, nc=64, d=32, M=4, n_base=2500, nq=16, efConstruction=40, empty_frac=0.2)
+    base.update(kw)
+    return synth.make_corpus(**base)
+
+
+# ---------------------------------------------------------------------------------------------- formats (CPU)
+@pytest.mark.parametrize("nsubc", [0, 4])
+def test_index_file_written_by_oracle_roundtrips_through_the_class(tmp_path, nsubc):
+    c = small(nsubc=nsubc)
+    src, dst = str(tmp_path / "a.index"), str(tmp_path / "b.index")
+    synth.oracle_index(c).write(src)
+    tool("index_roundtrip", "grouping" if nsubc else "ivf", c["d"], c["nc"], c["code_size"], nsubc, src, dst)
+    assert open(src, "rb").read() == open(dst, "rb").read()
+
+
+def test_hnsw_files_roundtrip_and_host_construction_equals_oracle(tmp_path):
+    rng = np.random.default_rng(4)
+    cents = synth.sift_like(rng, 300, 32)
+    g = orc.Hnsw.build(cents, M=6, efConstruction=50)
+    pi, pe, pd = (str(tmp_path / n) for n in ("i", "e", "c.fvecs"))
+    g.save(pi, pe)
+    hostio.write_xvecs(pd, cents)
+    tool("hnsw_roundtrip", pi, pd, pe, pi + "2", pe + "2")
+    assert open(pi, "rb").read() == open(pi + "2", "rb").read()
+    assert open(pe, "rb").read() == open(pe + "2", "rb").read()
+    # serial construction on the host reproduces the oracle's graph link for link
+    tool("hnsw_build", pd, 300, 32, 6, 50, pi + "3", pe + "3")
+    assert open(pi, "rb").read() == open(pi + "3", "rb").read()
+    assert open(pe, "rb").read() == open(pe + "3", "rb").read()
+
+
+def test_host_walk_equals_oracle(tmp_path):
+    rng = np.random.default_rng(5)
+    base = synth.sift_like(rng, 150, 32)
+    cents = np.concatenate([base, base[:40]])  # duplicates: exact ties
+    g = orc.Hnsw.build(cents, M=6, efConstruction=50)
+    pi, pe, pd, pq = (str(tmp_path / n) for n in ("i", "e", "c.fvecs", "q.fvecs"))
+    g.save(pi, pe)
+    hostio.write_xvecs(pd, cents)
+    q = (base[rng.choice(150, 20)] + rng.normal(0, 4, (20, 32))).astype(np.float32)
+    q[:4] = base[:4]
+    hostio.write_xvecs(pq, q)
+    for ef, k in [(8, 8), (30, 10), (64, 64)]:
+        out = str(tmp_path / "o.bin")
+        tool("hnsw_search", pi, pd, pe, pq, 20, ef, k, out)
+        raw = np.fromfile(out, np.uint8)
+        ids = raw[:20 * k * 4].view(np.uint32).reshape(20, k)
+        dist = raw[20 * k * 4:].view(np.float32).reshape(20, k)
+        for i in range(20):
+            rid, rd = g.search_knn(q[i], ef, k)
+            assert np.array_equal(ids[i, :len(rid)], rid)
+            assert np.array_equal(dist[i, :len(rid)].view(np.uint32), rd.view(np.uint32))
+
+
+def test_pq_and_opq_files_roundtrip(tmp_path):
+    rng = np.random.default_rng(6)
+    a, b = str(tmp_path / "pq"), str(tmp_path / "pq2")
+    hostio.write_pq(a, 32, 4, rng.normal(size=(4, 256, 8)).astype(np.float32))
+    tool("pq_roundtrip", a, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    a, b = str(tmp_path / "opq"), str(tmp_path / "opq2")
+    hostio.write_opq(a, synth.random_rotation(rng, 32))
+    tool("vt_roundtrip", a, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # a truncated / foreign file is refused loudly
+    open(a, "wb").write(b"nope")
+    r = subprocess.run([TOOL, "vt_roundtrip", a, b], capture_output=True, text=True)
+    assert r.returncode == 1 and "LTra" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests"), reason="reference tree not present (GPU box)")
+def test_reference_drivers_compile_unchanged_against_these_headers():
+    """Source compatibility of the drop-in surface: every driver of the reference parses AND links."""
+    import glob
+    drivers = sorted(glob.glob("/root/reference/tests/*.cpp"))
+    assert len(drivers) == 12
+    for f in drivers:
+        r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-w", "-fopenmp", "-I" + os.path.join(ROOT, "include"), f],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (f, r.stderr[-1500:])
+
+
+# ---------------------------------------------------------------------------------------------- search (GPU)
+def _class_search(tmp_path, c, nprobe, max_codes, ef, pruning, k=1):
+    p = hostio.dump_corpus(c, str(tmp_path))
+    out = str(tmp_path / "res.bin")
+    nq = len(c["queries"])
+    tool("search", "grouping" if c["nsubc"] else "ivf", c["d"], c["nc"], c["code_size"], c["nsubc"], p["centroids"],
+         p["info"], p["edges"], p["pq"], p["norm_pq"], p["opq"], p["index"], p["queries"], nq, k, nprobe, max_codes, ef,
+         int(pruning), out)
+    raw = np.fromfile(out, np.uint8)
+    lab = raw[:2 * nq * k * 8].view(np.int64).reshape(2, nq, k)
+    dist = raw[2 * nq * k * 8:].view(np.float32).reshape(2, nq, k)
+    return lab, dist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw,nprobe,max_codes,ef,pruning", [
+    (dict(seed=71, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80), 8, 1500, 32, False),
+    (dict(seed=72, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80, opq=True), 8, 1500, 32, False),
+    (dict(seed=73, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80, nsubc=8), 8, 700, 40, True),
+    (dict(seed=74, nc=128, d=96, M=8, n_base=6000, nq=32, efConstruction=80, nsubc=8, opq=True), 8, 900, 40, False),
+])
+def test_class_search_equals_oracle(tmp_path, kw, nprobe, max_codes, ef, pruning):
+    """The drivers' load sequence (build_quantizer from files, read_ProductQuantizer, read, rotate_quantizer) then
+    search() one query per call and search_batch(): labels and distances identical to the oracle."""
+    # the corpus generator rotates the graph in place for OPQ; the centroid FILE must hold unrotated centroids
+    c = synth.make_corpus(**kw)
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=pruning)
+    ref_d, ref_l, _, _, _ = ox.search_batch(c["queries"], k=1)
+    lab, dist = _class_search(tmp_path, c, nprobe, max_codes, ef, pruning)
+    for mode in (0, 1):  # per-query calls, batch
+        assert np.array_equal(lab[mode], ref_l)
+        assert np.array_equal(dist[mode].view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_class_search_k10_is_a_heap_with_the_right_content(tmp_path):
+    c = synth.make_corpus(seed=71, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80)
+    ox = synth.oracle_index(c)
+    ox.set_params(8, 1500, 32)
+    ref_d, ref_l, _, _, _ = ox.search_batch(c["queries"], k=10)
+    lab, dist = _class_search(tmp_path, c, 8, 1500, 32, False, k=10)
+    for i in range(len(ref_l)):
+        assert sorted(zip(dist[0][i].tolist(), lab[0][i].tolist())) == sorted(zip(ref_d[i].tolist(), ref_l[i].tolist()))
+        v = dist[0][i]
+        assert all(v[(j - 1) // 2] >= v[j] for j in range(1, 10))  # max-heap array, as faiss leaves it
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRV, "test_ivfhnsw_deep1b")),
+                    reason="reference drivers not built (make -C oracle ref_drivers needs /root/reference)")
+@pytest.mark.parametrize("driver,opq", [("test_ivfhnsw_deep1b", False), ("test_ivfhnsw_deep1b", True),
+                                        ("test_ivfhnsw_grouping_deep1b", False)])
+def test_reference_driver_binary_runs_on_this_library(tmp_path, driver, opq):
+    """The reference's own driver (built unchanged, oracle/Makefile ref_drivers) loads synthetic files in the
+    reference's formats and searches through this repo's device path: the Recall@1 it prints must be the recall of
+    the oracle's labels."""
+    grouping = "grouping" in driver
+    c = synth.make_corpus(seed=81, nc=128, d=96, M=8, n_base=8000, nq=64, efConstruction=80, opq=opq,
+                          nsubc=8 if grouping else 0)
+    nprobe, max_codes, ef = 8, 1200, 32
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+    _, ref_l, _, _, _ = ox.search_batch(c["queries"], k=1)
+    gt = ((c["queries"][:, None, :] - c["base"][None, :, :]) ** 2).sum(2).argsort(1)[:, :5].astype(np.int32)
+    want = float((ref_l[:, 0] == gt[:, 0]).mean())
+    p = hostio.dump_corpus(c, str(tmp_path))
+    hostio.write_xvecs(str(tmp_path / "gt.ivecs"), gt)
+    open(tmp_path / "precomputed_idxs.ivecs", "wb").close()
+    args = ["-M", 16, "-efConstruction", 80, "-nb", 8000, "-nt", 1000, "-nsubt", 1000, "-nc", c["nc"], "-nq", 64,
+            "-ngt", 5, "-d", 96, "-code_size", 8, "-opq", "on" if opq else "off", "-k", 1, "-nprobe", nprobe,
+            "-max_codes", max_codes, "-efSearch", ef, "-path_base", "unused", "-path_learn", "unused",
+            "-path_q", p["queries"], "-path_gt", str(tmp_path / "gt.ivecs"), "-path_centroids", p["centroids"],
+            "-path_precomputed_idx", str(tmp_path / "precomputed_idxs.ivecs"), "-path_info", p["info"],
+            "-path_edges", p["edges"], "-path_pq", p["pq"], "-path_opq_matrix", p["opq"], "-path_norm_pq", p["norm_pq"],
+            "-path_index", p["index"]]
+    if grouping:
+        args += ["-nsubc", 8, "-pruning", "on"]
+    r = subprocess.run([os.path.join(REF_DRV, driver)] + [str(a) for a in args], capture_output=True, text=True,
+                       cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:] + r.stdout[-2000:]
+    m = re.search(r"Recall@1: ([0-9.eE+-]+)", r.stdout)
+    assert m, r.stdout[-2000:]
+    assert abs(float(m.group(1)) - want) < 1e-6, (m.group(1), want)
