@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="write rank 0's labels/distances of the last step to this .npz")
     args = ap.parse_args()
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # oracle threads must not spin inside a CPU quota
@@ -69,11 +70,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # rehearsal on a single-GPU box: IVFHNSW_BENCH_BACKEND=gloo puts every rank on GPU 0 and runs the same
+    # collectives over gloo (RCCL refuses two ranks on one device); the driver's real runs use nccl (= RCCL).
+    backend = os.environ.get("IVFHNSW_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_total, nc, d, M, nprobe, max_codes, ef, nq = WORKLOADS[args.workload]
     t0 = time.time()
@@ -137,8 +146,9 @@ def main():
     g.set_profiling(False)
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    nc_t = torch.tensor([float(ncodes)], dtype=torch.float64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    nc_t = torch.tensor([float(ncodes)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(nc_t, op=dist.ReduceOp.SUM)
@@ -148,6 +158,8 @@ def main():
     lab_gpu = d_lab.cpu().numpy()[:, 0]
     dist_gpu = d_dist.cpu().numpy()[:, 0]
 
+    if rank == 0 and args.dump:
+        np.savez(args.dump, labels=lab_gpu, dist=dist_gpu)
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

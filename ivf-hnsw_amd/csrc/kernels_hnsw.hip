@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 int coarse_slots_for(int ef)
 {
     const int nch = (ef + 63) / 64;
-    const int waves_per_simd = nch <= 8 ? 4 : 3;
+    const int waves_per_simd = nch <= 4 ? 8 : (nch <= 8 ? 4 : 3); // upper bound; extra blocks just find the queue empty
     return 256 * 4 * waves_per_simd;
 }
 
@@ -387,21 +387,34 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
     // tuning knob (A/B on the device).  Measured on MI355X (100M / 2^17-centroid workload, ef 80): the
     // walk is bound by per-wave instruction issue, and 4 waves/SIMD with ~110 VGPRs (2.05 ms per 10 k
     // queries) beats 8 waves/SIMD with ~55 (2.6 ms), so 4 is the default.
-    static const bool occ8 = [] {
+    static const int occ = [] {
         const char *e = getenv("IVFHNSW_WALK_OCC");
-        return e && atoi(e) >= 8;
+        const int v = e ? atoi(e) : 4;
+        return (v == 5 || v == 6 || v == 8) ? v : 4;
     }();
+#define IVFHNSW_WALK_N(N)              \
+    do {                               \
+        if (occ == 8)                  \
+            IVFHNSW_WALK(N, 8);        \
+        else if (occ == 6)             \
+            IVFHNSW_WALK(N, 6);        \
+        else if (occ == 5)             \
+            IVFHNSW_WALK(N, 5);        \
+        else                           \
+            IVFHNSW_WALK(N, 4);        \
+    } while (0)
     if (nch <= 1) {
-        if (occ8) IVFHNSW_WALK(1, 8); else IVFHNSW_WALK(1, 4);
+        IVFHNSW_WALK_N(1);
     } else if (nch <= 2) {
-        if (occ8) IVFHNSW_WALK(2, 8); else IVFHNSW_WALK(2, 4);
+        IVFHNSW_WALK_N(2);
     } else if (nch <= 4) {
-        if (occ8) IVFHNSW_WALK(4, 8); else IVFHNSW_WALK(4, 4);
+        IVFHNSW_WALK_N(4);
     } else if (nch <= 8) {
         IVFHNSW_WALK(8, 4);
     } else {
         IVFHNSW_WALK(16, 4);
     }
+#undef IVFHNSW_WALK_N
 #undef IVFHNSW_WALK
     return hipGetLastError();
 }

@@ -310,7 +310,11 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
         __syncthreads();
         const uint32_t cl = s_lpos[0];
         const uint32_t b0 = max(cl, lo), b1 = min(ch, hi);
+        // the segment this lane is currently inside, kept in registers: positions only grow, so the LDS plan is
+        // consulted again only when a position runs past the segment's end
         uint32_t s = 0;
+        uint32_t seg_lo = 0, seg_hi = 0, seg_start = 0, seg_vpos = 0;
+        float seg_ct = 0.f;
         for (uint32_t base = b0; base < b1; base += THREADS * U) {
             uint32_t w[U][CS / 4];
             uint32_t nb[U], vp[U];
@@ -321,28 +325,35 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                 const uint32_t p = base + u * THREADS + tid;
                 ok[u] = p < b1;
                 if (ok[u]) {
-                    if constexpr (SEGCAP <= 64) {
-                        while (p >= s_lpos[s + 1])
-                            s++;
-                    } else {
-                        // first s with s_lpos[s+1] > p, searched in (s, cn)
-                        uint32_t a = s, b = cn - 1;
-                        while (a < b) {
-                            const uint32_t mid = (a + b) >> 1;
-                            if (s_lpos[mid + 1] > p)
-                                b = mid;
-                            else
-                                a = mid + 1;
+                    if (p >= seg_hi) {
+                        if constexpr (SEGCAP <= 64) {
+                            while (p >= s_lpos[s + 1])
+                                s++;
+                        } else {
+                            // first s with s_lpos[s+1] > p, searched in (s, cn)
+                            uint32_t a = s, b = cn - 1;
+                            while (a < b) {
+                                const uint32_t mid = (a + b) >> 1;
+                                if (s_lpos[mid + 1] > p)
+                                    b = mid;
+                                else
+                                    a = mid + 1;
+                            }
+                            s = a;
                         }
-                        s = a;
+                        const Seg sg = s_seg[s];
+                        seg_lo = s_lpos[s];
+                        seg_hi = seg_lo + sg.len;
+                        seg_start = sg.start;
+                        seg_vpos = sg.vpos;
+                        seg_ct = sg.cterm;
                     }
-                    const Seg sg = s_seg[s];
-                    const uint32_t off = p - s_lpos[s];
-                    const uint32_t gi = sg.start + off;
+                    const uint32_t off = p - seg_lo;
+                    const uint32_t gi = seg_start + off;
                     load_code_words<CS>(codes, gi, w[u]);
                     nb[u] = norm_codes[gi];
-                    vp[u] = sg.vpos + off;
-                    ct[u] = sg.cterm;
+                    vp[u] = seg_vpos + off;
+                    ct[u] = seg_ct;
                 }
             }
 #pragma unroll
@@ -395,9 +406,23 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
 {
     dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
-#define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                                                                          \
-    hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, 4, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
+#define IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, UU)                                                                     \
+    hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, UU, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
                        luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64)
+#define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                 \
+    do {                                                   \
+        if (unroll == 2)                                   \
+            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 2);       \
+        else if (unroll == 8)                              \
+            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 8);       \
+        else                                               \
+            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 4);       \
+    } while (0)
+    static const int unroll = [] {
+        const char *e = getenv("IVFHNSW_SCAN_U");
+        const int v = e ? atoi(e) : 4;
+        return (v == 2 || v == 8) ? v : 4;
+    }();
     const int rep = CS <= 16 ? scan_rep_choice() : 1;
     if (max_seg <= 64) {
         if (rep == 4)
@@ -410,6 +435,7 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         IVFHNSW_SCAN(1024, 1, 256);
     }
 #undef IVFHNSW_SCAN
+#undef IVFHNSW_SCAN_U
     return hipGetLastError();
 }
 

@@ -55,6 +55,29 @@ def merge_keys_labels(keys, labels_of_owner, group=None):
     dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
 
 
+def _all_gather_rows(buf, rank, per, group):
+    """In-place all-gather of `per` rows per rank into buf (RCCL: ncclAllGather in place)."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(buf, buf[rank * per:(rank + 1) * per], group=group)
+    else:  # gloo (CPU tests / single-GPU rehearsal): stage through the host
+        host = buf.cpu()
+        parts = [host[r * per:(r + 1) * per].clone() for r in range(dist.get_world_size(group))]
+        dist.all_gather(parts, host[rank * per:(rank + 1) * per].clone(), group=group)
+        for r, t in enumerate(parts):
+            buf[r * per:(r + 1) * per].copy_(t)
+
+
+def _all_reduce(t, op, group):
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=op, group=group)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+
+
 class ShardedSearcher:
     """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller."""
 
@@ -75,11 +98,11 @@ class ShardedSearcher:
             g.coarse_dev(self.hi - self.lo, d_q[self.lo:self.hi], self.nprobe, efSearch,
                          self.cid[r * per:], self.cd[r * per:])
         if self.world > 1:
-            dist.all_gather_into_tensor(self.cid, self.cid[r * per:(r + 1) * per], group=self.group)
-            dist.all_gather_into_tensor(self.cd, self.cd[r * per:(r + 1) * per], group=self.group)
+            _all_gather_rows(self.cid, r, per, self.group)
+            _all_gather_rows(self.cd, r, per, self.group)
         g.search_dev(self.nq, 1, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
                      d_coarse_dists=self.cd, do_pruning=do_pruning, d_out_keys=self.keys)
         if self.world > 1:
-            dist.all_reduce(self.keys, op=dist.ReduceOp.MIN, group=self.group)
+            _all_reduce(self.keys, dist.ReduceOp.MIN, self.group)
             g.resolve_keys_dev(self.nq, 1, self.keys, d_dist, d_lab)
-            dist.all_reduce(d_lab, op=dist.ReduceOp.MAX, group=self.group)
+            _all_reduce(d_lab, dist.ReduceOp.MAX, self.group)
