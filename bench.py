@@ -8,10 +8,12 @@ Workload (BASELINE.json configs[1]): synthetic 100M x 128-d, 2^17 centroids, PQ1
 batch, at the paper operating point (nprobe, max_codes, efSearch) = (32, 10000, 80)
 (reference examples/run_sift1b.sh:37-43).  SIFT1B-shaped synthetic data: see tests/synth.py.
 
-N > 1 (strong scaling): the inverted lists are sharded list-wise over the ranks
-(c % N == rank), every rank holds the replicated tables; the coarse walk is split over the ranks by
-query and all-gathered, every rank scans its shard for all queries, and the packed (distance, scan
-position) keys are MIN-all-reduced over RCCL, labels MAX-all-reduced.
+N > 1 (WEAK scaling): the per-GPU work is fixed -- every GPU holds 100M codes and walks 10 k
+queries -- so N GPUs search an N x 100M corpus with N x 2^17 centroids for N x 10 k queries per step (N = 8:
+800M vectors, 2^20 centroids: the SIFT1B shape of BASELINE.json configs[3]/[4]).  The inverted lists are sharded
+list-wise over the ranks (c % N == rank), every rank holds the replicated tables and graph; the coarse walk is
+split over the ranks by query and all-gathered, every rank scans its shard for ALL queries, and the packed
+(distance, scan position) keys are MIN-all-reduced over RCCL, labels MAX-all-reduced.
 
 Prints ONE JSON line on rank 0.
 """
@@ -50,6 +52,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=int, default=0,
+                    help="corpus / centroid / batch multiplier; default = number of GPUs (weak scaling)")
     ap.add_argument("--dump", default=None, help="write rank 0's labels/distances of the last step to this .npz")
     args = ap.parse_args()
 
@@ -85,6 +89,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_total, nc, d, M, nprobe, max_codes, ef, nq = WORKLOADS[args.workload]
+    scale = args.scale if args.scale > 0 else world
+    n_total, nc, nq = n_total * scale, nc * scale, nq * scale
+    if n_total >= 2 ** 32:
+        raise SystemExit("corpus of %d vectors does not fit uint32 ids" % n_total)
     t0 = time.time()
     tb = synth.make_throughput_tables(args.seed, nc, d, M, n_total)
     rng = np.random.default_rng(args.seed + 1)
@@ -98,13 +106,8 @@ def main():
     g = pkg.GpuIndex(local_rank)
     code_seed = args.seed + 7
     t0 = time.time()
-    if world == 1:
-        g.upload_ivf_synthetic(d, M, tb["offsets"], centroid_norms, tb["pq_centroids"], tb["norm_table"], code_seed)
-    else:
-        ids_s, codes_s, ncodes_s = synth.synthetic_codes_shard(code_seed, tb["offsets"], M, rank, world)
-        g.upload_ivf(d, M, tb["offsets"], ids_s, codes_s, ncodes_s, centroid_norms, tb["pq_centroids"],
-                     tb["norm_table"], shard_rank=rank, shard_world=world)
-        del ids_s, codes_s, ncodes_s
+    g.upload_ivf_synthetic(d, M, tb["offsets"], centroid_norms, tb["pq_centroids"], tb["norm_table"], code_seed,
+                           shard_rank=rank, shard_world=world)
     g.upload_quantizer(counts, links, tb["centroids"], 0)
     if rank == 0:
         log("[bench] corpus on device: %.1fs, %.2f GB held" % (time.time() - t0, g.memory_bytes() / 1e9))
@@ -177,12 +180,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload, "n_vectors": n_total, "nc": nc, "d": d, "code_size": M,
+                "workload": args.workload + ("" if scale == 1 else " x%d" % scale), "n_vectors": n_total, "nc": nc, "d": d, "code_size": M,
                 "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef, "batch": nq, "k": 1,
                 "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq, 1),
                 "sharding": "replicas=1" if world == 1 else "lists c%%%d, RCCL min-merge" % world,
@@ -195,7 +198,7 @@ def main():
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
         }
 
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and scale == 1 and not args.no_cpu_baseline:
             # the oracle (a port of the reference's CPU path) on the same corpus, bounded sample of the same batch
             from oracle import orc
             t0 = time.time()

@@ -74,7 +74,8 @@ int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *desc);
 
 /* Same tables, but codes / norm codes are generated on the device (uniform bytes from `seed`) and
  * ids are the running index: the SIFT1B-shaped synthetic corpus of SURVEY 8d for sizes that never
- * exist on the host.  desc->ids/codes/norm_codes are ignored. */
+ * exist on the host.  desc->ids/codes/norm_codes are ignored.  With shard_world > 1 the shard receives
+ * exactly the bytes and ids its lists have in the unsharded corpus. */
 int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *desc, uint64_t seed);
 
 /* The extra members of IndexIVF_HNSW_Grouping (IndexIVF_HNSW_Grouping.h:17-22,61) after read()

@@ -164,9 +164,10 @@ class GpuIndex:
                                 norm_codes, shard_rank, shard_world)
         _check(lib().ivfhnsw_gpu_upload_ivf(self._h, C.byref(desc)))
 
-    def upload_ivf_synthetic(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, seed, opq_A=None):
+    def upload_ivf_synthetic(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, seed, opq_A=None,
+                             shard_rank=0, shard_world=1):
         desc, keep = self._desc(d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, None, None,
-                                None, 0, 1)
+                                None, shard_rank, shard_world)
         _check(lib().ivfhnsw_gpu_upload_ivf_synthetic(self._h, C.byref(desc), seed))
 
     def upload_grouping(self, nsubc, alphas, nn_centroid_idxs, subgroup_sizes, inter_centroid_dists):

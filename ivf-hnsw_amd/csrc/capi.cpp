@@ -387,8 +387,6 @@ int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, 
         return rc;
     if ((rc = check_desc(d, false)))
         return rc;
-    if (d->shard_world != 1)
-        return fail(IVFHNSW_ERR_INVALID, "synthetic corpus: generate per shard with shard_world == 1 tables");
     h->has_ivf = false;
     std::vector<uint32_t> loff;
     uint64_t n_local = 0;
@@ -400,9 +398,10 @@ int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, 
         return rc;
     if ((rc = h->ids.ensure(n_local * sizeof(uint32_t))))
         return rc;
-    HIP_TRY(launch_fill_bytes(h->stream, h->codes.as<uint8_t>(), n_local * d->code_size, seed));
-    HIP_TRY(launch_fill_bytes(h->stream, h->ncodes.as<uint8_t>(), n_local, seed ^ 0x6e6f726d6e6f726dull));
-    HIP_TRY(launch_fill_iota(h->stream, h->ids.as<uint32_t>(), n_local, 0));
+    if (d->offsets[d->nc] > 0xffffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "synthetic corpus: more than 2^32 vectors (ids are uint32)");
+    HIP_TRY(launch_fill_lists(h->stream, h->t, h->codes.as<uint8_t>(), h->ncodes.as<uint8_t>(), h->ids.as<uint32_t>(),
+                              seed, seed ^ 0x6e6f726d6e6f726dull));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->t.codes = h->codes.as<uint8_t>();
     h->t.norm_codes = h->ncodes.as<uint8_t>();

@@ -96,6 +96,8 @@ constexpr uint32_t kStatusHnswTieOverflow = 1u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
+hipError_t launch_fill_lists(hipStream_t s, const IvfTables &t, uint8_t *codes, uint8_t *norm_codes, uint32_t *ids,
+                             uint64_t seed_codes, uint64_t seed_norms);
 // sum of PlanHdr.total / nseg over the batch into out[0], out[1]
 hipError_t launch_plan_totals(hipStream_t s, const PlanHdr *hdr, int nq, unsigned long long *out);
 

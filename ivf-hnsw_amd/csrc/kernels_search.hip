@@ -567,6 +567,39 @@ hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_
     return hipGetLastError();
 }
 
+// Sharded form: one workgroup per owned list; list c's bytes are the bytes of the unsharded stream at its GLOBAL
+// offset, so a shard holds exactly the slice of the single-GPU corpus it owns.
+__global__ void fill_lists_kernel(IvfTables t, uint8_t *__restrict__ codes, uint8_t *__restrict__ norm_codes,
+                                  uint32_t *__restrict__ ids, unsigned long long seed_codes,
+                                  unsigned long long seed_norms)
+{
+    const int cs4 = t.M / 4; // dwords per code
+    for (uint32_t c = t.shard_rank + blockIdx.x * t.shard_world; c < t.nc; c += gridDim.x * t.shard_world) {
+        const unsigned long long g0 = t.goff[c], n = t.goff[c + 1] - g0;
+        const uint32_t l0 = t.loff[c];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (size_t)l0 * t.M);
+        for (unsigned long long j = threadIdx.x; j < n * cs4; j += blockDim.x) {
+            const unsigned long long k = g0 * cs4 + j; // global dword index of the code stream
+            const unsigned long long v = mix64(seed_codes + ((k >> 1) + 1) * 0x9E3779B97F4A7C15ull);
+            dst[j] = (uint32_t)(v >> (32 * (k & 1)));
+        }
+        for (unsigned long long j = threadIdx.x; j < n; j += blockDim.x) {
+            const unsigned long long b = g0 + j;
+            const unsigned long long v = mix64(seed_norms + ((b >> 3) + 1) * 0x9E3779B97F4A7C15ull);
+            norm_codes[l0 + j] = (uint8_t)(v >> (8 * (b & 7)));
+            ids[l0 + j] = (uint32_t)b;
+        }
+    }
+}
+
+hipError_t launch_fill_lists(hipStream_t s, const IvfTables &t, uint8_t *codes, uint8_t *norm_codes, uint32_t *ids,
+                             uint64_t seed_codes, uint64_t seed_norms)
+{
+    hipLaunchKernelGGL(fill_lists_kernel, dim3(256 * 8), dim3(256), 0, s, t, codes, norm_codes, ids,
+                       (unsigned long long)seed_codes, (unsigned long long)seed_norms);
+    return hipGetLastError();
+}
+
 __global__ void fill_iota_kernel(uint32_t *__restrict__ dst, size_t n, uint32_t first)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

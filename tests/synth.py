@@ -216,7 +216,7 @@ def synthetic_codes(seed, offsets, code_size):
     return ids, codes, norm_codes
 
 
-def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=8192):
+def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=4096):
     """A navigable small-world graph for throughput runs: each node links to its M nearest neighbours, then
     reverse links are added up to maxM (the same degree bounds the reference's construction keeps,
     IndexIVF_HNSW.cpp:50, hnswalg.cpp:171-184).  The reference-identical serial construction (orc.Hnsw.build,
