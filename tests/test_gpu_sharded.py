@@ -67,3 +67,40 @@ def test_sharded_equals_unsharded(gpu, world, grouping):
         dist = dd
     assert np.array_equal(label.cpu().numpy(), ref_l)
     assert np.array_equal(dist.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+def test_sharded_device_generated_corpus(gpu):
+    """ivfhnsw_gpu_upload_ivf_synthetic with shard_world > 1: every shard generates exactly its slice of the
+    unsharded stream, so the merged result equals the unsharded device result and the oracle."""
+    import torch
+    t = synth.make_throughput_tables(seed=5, nc=512, d=128, M=16, n_total=200000)
+    ids, codes, norm_codes = synth.synthetic_codes(99, t["offsets"], 16)
+    gr = synth.orc.Hnsw.build(t["centroids"], M=16, efConstruction=60)
+    t.update(ids=ids, codes=codes, norm_codes=norm_codes, centroid_norms=gr.centroid_norms(), graph=gr)
+    ox = synth.oracle_index(t)
+    ox.set_params(16, 5000, 40)
+    rng = np.random.default_rng(3)
+    q = (t["centroids"][rng.choice(512, 64)] + rng.normal(0, 10, size=(64, 128))).astype(np.float32)
+    ref_d, ref_l, cid, cd, _ = ox.search_batch(q, k=1)
+    dev = torch.device("cuda", 0)
+    d_q, d_cid, d_cd = (torch.from_numpy(a).to(dev) for a in (q, cid.astype(np.int32), cd))
+    world, nq = 3, 64
+    merged, shards = None, []
+    for r in range(world):
+        g = gpu()
+        g.upload_ivf_synthetic(128, 16, t["offsets"], t["centroid_norms"], t["pq_centroids"], t["norm_table"], seed=99,
+                               shard_rank=r, shard_world=world)
+        dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
+        ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+        kk = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+        g.search_dev(nq, 1, d_q, dd, ll, 16, 5000, d_coarse_ids=d_cid, d_coarse_dists=d_cd, d_out_keys=kk)
+        g.sync()
+        merged = kk if merged is None else torch.minimum(merged, kk)
+        shards.append((g, dd, ll))
+    label = torch.full((nq, 1), -1, dtype=torch.int64, device=dev)
+    for g, dd, ll in shards:
+        g.resolve_keys_dev(nq, 1, merged, dd, ll)
+        g.sync()
+        label = torch.maximum(label, ll)
+    assert np.array_equal(label.cpu().numpy(), ref_l)
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
