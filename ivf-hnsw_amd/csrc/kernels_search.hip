@@ -18,7 +18,8 @@ namespace ivfhnsw_gpu_impl {
 // IndexIVF_HNSW.cpp:240; faiss hands this to sgemm, whose order is unspecified).
 // One block per query, one thread per output dim; At is A transposed so reads coalesce.
 // ---------------------------------------------------------------------------------------------
-__global__ void opq_kernel(const float *__restrict__ At, const float *__restrict__ x, float *__restrict__ y, int d)
+__global__ void opq_kernel(const float *__restrict__ At, const float *__restrict__ x, float *__restrict__ y, int nq,
+                           int d)
 {
     extern __shared__ float s_x[];
     const int q = blockIdx.x;
@@ -33,12 +34,57 @@ __global__ void opq_kernel(const float *__restrict__ At, const float *__restrict
     }
 }
 
+// Batched form on the matrix cores -- the one true dense contraction on the path (nq x d times d x d).
+// v_mfma_f32_32x32x2_f32 computes D = A*B + C as a k-ordered fmaf chain per element, one rounding per step
+// (MI355X guide: "bit-for-bit a k-ordered f32 fmaf chain"), which is exactly the order opq_kernel and the
+// oracle use, so the result is bit-identical to the scalar form.
+// One 256-thread workgroup = 32 queries x up to 128 output dims: wave w owns the 32x32 tile of output dims
+// [32w, 32w+32).  MFMA operand A = x (row = query, k), operand B = At (k, output dim): lane l feeds
+// x[q0 + l%32][k0 + l/32] and At[k0 + l/32][i0 + l%32]; the query tile sits in LDS with a padded row so the
+// 32 lanes of a read hit 32 banks.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void opq_mfma_kernel(const float *__restrict__ At, const float *__restrict__ x,
+                                                       float *__restrict__ y, int nq, int d)
+{
+    extern __shared__ float s_xt[]; // [32][d + 1]
+    const int q0 = blockIdx.x * 32;
+    const int ld = d + 1;
+    for (int i = threadIdx.x; i < 32 * d; i += 256) {
+        const int r = i / d, c = i - r * d;
+        const int q = min(q0 + r, nq - 1); // rows past the batch replicate the last query; never stored
+        s_xt[r * ld + c] = x[(size_t)q * d + c];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 31, kk = lane >> 5;
+    for (int i0 = (blockIdx.y * 4 + wave) * 32; i0 < d; i0 += gridDim.y * 128) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k0 = 0; k0 < d; k0 += 2) {
+            const float a = s_xt[m * ld + k0 + kk];
+            const float b = At[(size_t)(k0 + kk) * d + i0 + m];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk; // C/D layout of the 32x32 MFMA
+            if (q0 + row < nq)
+                y[(size_t)(q0 + row) * d + i0 + m] = acc[r];
+        }
+    }
+}
+
 hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, int nq, int d)
 {
     if (nq == 0)
         return hipSuccess;
+    if (d % 32 == 0 && d <= 2048) {
+        const size_t shm = (size_t)32 * (d + 1) * sizeof(float);
+        hipLaunchKernelGGL(opq_mfma_kernel, dim3((nq + 31) / 32, (d + 127) / 128), dim3(256), shm, s, At, x, y, nq, d);
+        return hipGetLastError();
+    }
     int threads = d < 256 ? ((d + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(opq_kernel, dim3(nq), dim3(threads), d * sizeof(float), s, At, x, y, d);
+    hipLaunchKernelGGL(opq_kernel, dim3(nq), dim3(threads), d * sizeof(float), s, At, x, y, nq, d);
     return hipGetLastError();
 }
 
