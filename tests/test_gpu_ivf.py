@@ -131,3 +131,19 @@ def test_synthetic_device_corpus_matches_host_stream(gpu):
     g.upload_ivf_synthetic(128, 16, t["offsets"], t["centroid_norms"], t["pq_centroids"], t["norm_table"], seed=99)
     dist, lab = g.search(q, 1, 16, 5000, coarse_ids=cid, coarse_dists=cd)
     _same(dist, lab, ref_d, ref_l)
+
+
+@pytest.mark.parametrize("d,M,nq", [(128, 16, 77), (96, 8, 33), (64, 8, 64), (48, 4, 19)])
+def test_opq_rotation_mfma_and_scalar_forms(gpu, d, M, nq):
+    """OPQ rotation (IndexIVF_HNSW.cpp:240): d % 32 == 0 takes the MFMA kernel (v_mfma_f32_32x32x2_f32 = k-ordered
+    fmaf chain), other d the scalar kernel; both must reproduce the oracle's fmaf chain bit for bit, including
+    batches that are not a multiple of the 32-query tile.  Checked through the whole search (a wrong rotation
+    changes the table and the distances)."""
+    c = corpus(seed=90 + d, nc=64, d=d, M=M, n_base=3000, nq=nq, opq=True, efConstruction=50)
+    ox = synth.oracle_index(c)
+    ox.set_params(8, 10 ** 9, 32)
+    ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=1)
+    g = gpu()
+    _upload(g, c)
+    dist, lab = g.search(c["queries"], 1, 8, 10 ** 9, coarse_ids=cid, coarse_dists=cd)
+    _same(dist, lab, ref_d, ref_l)
