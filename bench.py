@@ -36,6 +36,9 @@ WORKLOADS = {
     "synthetic-100M-pq16-nc131072-nprobe32": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
     "synthetic-10M-pq16-nc16384-nprobe32": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
     "synthetic-1M-pq8-nc4096-nprobe8": (1_000_000, 4096, 128, 8, 8, 10 ** 9, 40, 2000),
+    # Grouping + Pruning + OPQ at the reference's preset (examples/run_sift1b_grouping_OPQ.sh:7-53): nsubc 64
+    "grouping-100M-pq16-nc131072-nsubc64-opq-pruning": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
+    "grouping-10M-pq16-nc16384-nsubc64-opq-pruning": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
 }
 DEFAULT_WORKLOAD = "synthetic-100M-pq16-nc131072-nprobe32"
 
@@ -103,12 +106,28 @@ def main():
     if rank == 0:
         log("[bench] tables + graph: %.1fs (avg degree %.1f)" % (time.time() - t0, counts.mean()))
 
+    grouping = args.workload.startswith("grouping")
+    opq_A = None
+    vectors = tb["centroids"]
+    if grouping:
+        if world != 1:
+            raise SystemExit("the grouping workload is single-GPU for now")
+        gt = synth.make_grouping_tables(args.seed + 3, tb, 64, device=dev)
+        opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
+        # the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800)
+        from oracle import orc as _orc
+        rg = _orc.Hnsw.from_arrays(counts, links, tb["centroids"], 16, 0)
+        rg.rotate(opq_A)
+        vectors = rg.vectors.copy()
+        rg.free()
     g = pkg.GpuIndex(local_rank)
     code_seed = args.seed + 7
     t0 = time.time()
     g.upload_ivf_synthetic(d, M, tb["offsets"], centroid_norms, tb["pq_centroids"], tb["norm_table"], code_seed,
-                           shard_rank=rank, shard_world=world)
-    g.upload_quantizer(counts, links, tb["centroids"], 0)
+                           opq_A=opq_A, shard_rank=rank, shard_world=world)
+    g.upload_quantizer(counts, links, vectors, 0)
+    if grouping:
+        g.upload_grouping(64, gt["alphas"], gt["nn_centroid_idxs"], gt["subgroup_sizes"], gt["inter_centroid_dists"])
     if rank == 0:
         log("[bench] corpus on device: %.1fs, %.2f GB held" % (time.time() - t0, g.memory_bytes() / 1e9))
 
@@ -121,7 +140,7 @@ def main():
 
     def step():
         if world == 1:
-            g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, efSearch=ef)
+            g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         else:
             # coarse walk for this rank's slice of the batch -> all-gather -> scan own shard for all queries ->
             # MIN over shards of the packed keys -> owner resolves labels -> MAX over shards
@@ -203,10 +222,16 @@ def main():
             from oracle import orc
             t0 = time.time()
             ids_h, codes_h, ncodes_h = synth.synthetic_codes(code_seed, tb["offsets"], M)
-            graph = orc.Hnsw.from_arrays(counts, links, tb["centroids"], 16, 0)
-            ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h, ncodes_h,
-                           centroid_norms)
-            ox.set_params(nprobe, max_codes, ef)
+            graph = orc.Hnsw.from_arrays(counts, links, vectors, 16, 0)
+            if grouping:
+                ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h,
+                               ncodes_h, centroid_norms, opq_A=opq_A, nsubc=64, alphas=gt["alphas"],
+                               nn_centroid_idxs=gt["nn_centroid_idxs"], subgroup_sizes=gt["subgroup_sizes"],
+                               inter_centroid_dists=gt["inter_centroid_dists"])
+            else:
+                ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h,
+                               ncodes_h, centroid_norms)
+            ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
             log("[bench] host corpus for the CPU baseline: %.1fs" % (time.time() - t0))
             # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only spin
             try:

@@ -287,3 +287,40 @@ def synthetic_codes_shard(seed, offsets, code_size, rank, world):
         v = _mix64(nseed + (w + np.uint64(1)) * GOLDEN)
         norm_codes = ((v >> ((gidx % np.uint64(8)) * np.uint64(8))) & np.uint64(0xff)).astype(np.uint8)
     return gidx.astype(np.uint32), np.ascontiguousarray(codes), norm_codes
+
+
+def knn_ids_torch(centroids, k, device=None, chunk=4096):
+    """ids of the k nearest OTHER centroids of every centroid, ascending distance (brute force on the GPU)."""
+    import torch
+
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    x = torch.from_numpy(np.ascontiguousarray(centroids, np.float32)).to(dev)
+    n = x.shape[0]
+    sq = (x * x).sum(1)
+    out = torch.empty((n, k), dtype=torch.int64, device=dev)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        dist = sq[s:e, None] - 2.0 * (x[s:e] @ x.T) + sq[None, :]
+        dist[torch.arange(e - s, device=dev), torch.arange(s, e, device=dev)] = float("inf")
+        out[s:e] = dist.topk(k, dim=1, largest=False).indices
+    return out.cpu().numpy().astype(np.uint32)
+
+
+def make_grouping_tables(seed, tb, nsubc, device=None):
+    """Grouping tables for a throughput corpus (IndexIVF_HNSW_Grouping.h:17-22,61): the nsubc nearest centroids
+    of every centroid, alpha in [0, 0.5], each list split at random into nsubc sub-groups, and the exact
+    inter-centroid distances in the reference's float order (through the oracle)."""
+    rng = np.random.default_rng(seed)
+    nc = tb["nc"]
+    nn = knn_ids_torch(tb["centroids"], nsubc, device=device)
+    alphas = rng.uniform(0.0, 0.5, size=nc).astype(np.float32)
+    sizes = np.diff(tb["offsets"].astype(np.int64))
+    # multinomial split of every list into nsubc parts (vectorised: sorted uniform cut points)
+    cuts = np.sort(rng.integers(0, sizes[:, None] + 1, size=(nc, nsubc - 1)), axis=1)
+    edges = np.concatenate([np.zeros((nc, 1), np.int64), cuts, sizes[:, None]], axis=1)
+    sg = np.diff(edges, axis=1).astype(np.uint32)
+    assert (sg.sum(1) == sizes).all()
+    g = orc.Hnsw.from_arrays(np.zeros(nc, np.uint8), np.zeros((nc, 1), np.uint32), tb["centroids"], 1)
+    icd = g.inter_centroid_dists(nn)
+    g.free()
+    return dict(nsubc=nsubc, nn_centroid_idxs=nn, alphas=alphas, subgroup_sizes=sg, inter_centroid_dists=icd)
