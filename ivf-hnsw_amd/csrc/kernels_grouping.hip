@@ -22,9 +22,10 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
                                                            unsigned long long *__restrict__ keys, int k,
                                                            float *__restrict__ scratch)
 {
-    extern __shared__ __attribute__((aligned(16))) float s_q[];
+    extern __shared__ __attribute__((aligned(16))) float s_q[]; // query[d] | dist[64]
     const int lane = threadIdx.x;
     const int q = blockIdx.x;
+    float *s_dist = s_q + t.d;
     const int nsubc = g.nsubc;
     for (int j = lane; j < k; j += 64)
         keys[(size_t)q * k + j] = kKeyInit;
@@ -58,10 +59,32 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
                 const int subc = s0 + lane;
                 bool active = false;
                 float v = 0.f, qn = 0.f;
+                uint32_t nn = 0;
                 if (subc < nsubc && g.sub_sizes[(size_t)c * nsubc + subc] != 0) {
                     active = true;
-                    const uint32_t nn = g.nn_idx[(size_t)c * nsubc + subc];
-                    qn = l2_ref_order(gr.vectors + (size_t)nn * t.d, s_q, t.d);
+                    nn = g.nn_idx[(size_t)c * nsubc + subc];
+                }
+                // distances of the active sub-groups' neighbour centroids: a quad of lanes per row, 16 rows per
+                // pass, results handed back to the owning lane through LDS
+                {
+                    const unsigned long long am = __ballot(active);
+                    const int na = __popcll(am);
+                    for (int base = 0; base < na; base += 16) {
+                        const int r = base + (lane >> 2);
+                        const int src = r < na ? nth_set_bit(am, r) : 0;
+                        const uint32_t nnq = (uint32_t)__shfl((int)nn, src, 64);
+                        float dq = 0.f;
+                        if (r < na)
+                            dq = l2_ref_order_quad(gr.vectors + (size_t)nnq * t.d, s_q, t.d, lane & 3);
+                        if (r < na && (lane & 3) == 0)
+                            s_dist[src] = dq;
+                    }
+                    __syncthreads();
+                    if (active)
+                        qn = s_dist[lane];
+                    __syncthreads();
+                }
+                if (active) {
                     const float a = __fmul_rn(oma, g.inter_dists[(size_t)c * nsubc + subc]);
                     const float b = __fsub_rn(a, qn);
                     v = __fsub_rn(term1, __fmul_rn(alpha, b)); // Grouping.cpp:251-252
@@ -118,14 +141,34 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
                 if (do_pruning && row < p1_rows)
                     qs = qsd[(size_t)row * nsubc + subc];
                 scanned = !do_pruning || qs < threshold; // :308
+            }
+            // term2 needs ||x - y_N||^2: stored by pass 1 for its rows, evaluated now (quads) for the others
+            float qn2 = 0.f;
+            const bool need = scanned && !(do_pruning && row < p1_rows);
+            if (scanned && !need)
+                qn2 = qnv[(size_t)row * nsubc + subc];
+            {
+                const uint32_t nn = scanned ? g.nn_idx[(size_t)c * nsubc + subc] : 0u;
+                const unsigned long long am = __ballot(need);
+                const int na = __popcll(am);
+                if (na) {
+                    for (int base = 0; base < na; base += 16) {
+                        const int r = base + (lane >> 2);
+                        const int src = r < na ? nth_set_bit(am, r) : 0;
+                        const uint32_t nnq = (uint32_t)__shfl((int)nn, src, 64);
+                        float dq = 0.f;
+                        if (r < na)
+                            dq = l2_ref_order_quad(gr.vectors + (size_t)nnq * t.d, s_q, t.d, lane & 3);
+                        if (r < na && (lane & 3) == 0)
+                            s_dist[src] = dq;
+                    }
+                    __syncthreads();
+                    if (need)
+                        qn2 = s_dist[lane];
+                    __syncthreads();
+                }
                 if (scanned) {
-                    const uint32_t nn = g.nn_idx[(size_t)c * nsubc + subc];
-                    float qn;
-                    if (do_pruning && row < p1_rows)
-                        qn = qnv[(size_t)row * nsubc + subc];
-                    else
-                        qn = l2_ref_order(gr.vectors + (size_t)nn * t.d, s_q, t.d);
-                    const float term2 = __fmul_rn(alpha, __fsub_rn(qn, t.centroid_norms[nn])); // :318
+                    const float term2 = __fmul_rn(alpha, __fsub_rn(qn2, t.centroid_norms[nn])); // :318
                     cterm = __fadd_rn(term1, term2);
                 }
             }
@@ -170,7 +213,7 @@ hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTa
 {
     if (nq == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), t.d * sizeof(float), s, t, g, gr, xq, coarse_ids,
+    hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), (t.d + 64) * sizeof(float), s, t, g, gr, xq, coarse_ids,
                        coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr, max_seg,
                        reinterpret_cast<unsigned long long *>(keys), k, scratch);
     return hipGetLastError();

@@ -60,56 +60,6 @@ __device__ __forceinline__ unsigned long long lane_below_u64(unsigned long long 
     return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
-// position of the r-th (0-based) set bit of mask; r < popcount(mask)
-__device__ __forceinline__ int nth_set_bit(unsigned long long mask, int r)
-{
-    int pos = 0;
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) {
-        const int c = __popcll(mask & (((1ull << w) - 1ull) << pos));
-        if (c <= r) {
-            r -= c;
-            pos += w;
-        }
-    }
-    return pos;
-}
-
-// broadcast lane k of each quad to the whole quad (DPP quad_perm, no LDS)
-template <int K> __device__ __forceinline__ float quad_bcast(float v)
-{
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), K * 0x55, 0xf, 0xf, true));
-}
-
-// Exact reference distance (hnswalg.cpp:326-357) of one row evaluated by a QUAD of lanes: lane t of the quad
-// owns accumulators 2t and 2t+1 of the reference's eight, i.e. dims 8j+2t, 8j+2t+1 for j = 0..d/8-1 in
-// increasing order -- exactly the order each __m256 lane accumulates in.  All d/8 8-byte loads of a lane are
-// independent (one round trip per row); the quad then sums the eight accumulators left to right.
-// Every lane of the quad returns the distance.
-__device__ __forceinline__ float l2_ref_order_quad(const float *__restrict__ row, const float *sq, int d, int t)
-{
-    const float2 *r2 = reinterpret_cast<const float2 *>(row) + t;
-    const float2 *q2 = reinterpret_cast<const float2 *>(sq) + t;
-    float alo = 0.f, ahi = 0.f;
-    const int nj = d >> 3;
-#pragma unroll 16
-    for (int j = 0; j < nj; j++) {
-        const float2 y = r2[4 * j];
-        const float2 x = q2[4 * j];
-        const float d0 = __fsub_rn(x.x, y.x), d1 = __fsub_rn(x.y, y.y);
-        alo = __fadd_rn(alo, __fmul_rn(d0, d0));
-        ahi = __fadd_rn(ahi, __fmul_rn(d1, d1));
-    }
-    float r = __fadd_rn(quad_bcast<0>(alo), quad_bcast<0>(ahi));
-    r = __fadd_rn(r, quad_bcast<1>(alo));
-    r = __fadd_rn(r, quad_bcast<1>(ahi));
-    r = __fadd_rn(r, quad_bcast<2>(alo));
-    r = __fadd_rn(r, quad_bcast<2>(ahi));
-    r = __fadd_rn(r, quad_bcast<3>(alo));
-    r = __fadd_rn(r, quad_bcast<3>(ahi));
-    return r;
-}
-
 template <int NCH> struct RSet {
     unsigned long long r[NCH]; // entry i: lane i & 63, register i >> 6
 
