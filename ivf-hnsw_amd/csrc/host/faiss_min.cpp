@@ -3,7 +3,7 @@
 // published behaviour.  The search hot path does NOT run through here -- it runs on the device -- these
 // functions serve file I/O, centroid rotation at load time and construction-side callers.
 //
-// Built with -ffp-contract=off: float orders below match oracle/ and the kernels.
+// Built with -ffp-contract=off: the float orders below are the ones the device kernels use.
 #include <faiss/Heap.h>
 #include <faiss/ProductQuantizer.h>
 #include <faiss/VectorTransform.h>
