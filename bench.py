@@ -190,6 +190,15 @@ def main():
         scan_avg_ms = scan_ms / max(1, scan_n)
         bytes_per_code = M + 1  # PQ code + norm code
         achieved = bytes_per_code * ncodes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+        # HBM bytes per launch of the scan kernel, measured by the rocprofv3 PMC passes committed under profiles/
+        # (bench.py cannot collect counters itself); only reported for the workload they were taken on.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
+            if tj.get("workload") == args.workload and scale == 1 and world == 1:
+                traffic = round(tj["bytes_per_launch"] / 1e9, 4)
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak",
             "value": round(qps, 1),
@@ -211,7 +220,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": "scan_k1_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/scan_traffic.json)",
+                "algorithmic_gb_per_launch": round(bytes_per_code * ncodes / 1e9, 4),
                 "bytes_per_code": bytes_per_code, "codes_per_launch": ncodes, "avg_launch_ms": round(scan_avg_ms, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
