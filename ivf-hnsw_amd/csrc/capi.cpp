@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -505,19 +506,37 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
                     efSearch, nprobe);
     if (efSearch > 1024)
         return fail(IVFHNSW_ERR_INVALID, "efSearch %zu > 1024 unsupported on the device", efSearch);
+    if (h->gr.d > 128)
+        return fail(IVFHNSW_ERR_INVALID, "d %d > 128 unsupported by the device walk (SIFT is 128-d, DEEP 96-d)", h->gr.d);
     if (nq == 0)
         return IVFHNSW_OK;
     if (nq > 0x7fffffffull)
         return fail(IVFHNSW_ERR_INVALID, "nq too large");
-    // one visited bitmap per resident wavefront slot
+    // one visited bitmap per query in flight
     const size_t words = ((((size_t)h->gr.n + 31) / 32) + 3) & ~(size_t)3;
-    const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
-    if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
-        return rc;
+    // IVFHNSW_WALK=4 selects the four-queries-per-wavefront kernel (kernels_hnsw4.hip): exact, but measured
+    // slower (3.3 vs 2.05 ms per 10 k queries) -- kept for further work, off by default
+    static const bool one_per_wave = [] {
+        const char *e = getenv("IVFHNSW_WALK");
+        return !(e && atoi(e) == 4);
+    }();
     StageScope sc(h, IVFHNSW_STAGE_COARSE);
-    HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                          d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
-                          h->w_status.as<uint32_t>() + 1));
+    if (efSearch <= 256 && !one_per_wave) {
+        // four queries per wavefront (kernels_hnsw4.hip)
+        const int nwaves = (int)std::min<size_t>((nq + 3) / 4, (size_t)coarse4_waves_resident());
+        if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nwaves * 4)))
+            return rc;
+        HIP_TRY(launch_coarse4(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
+                               d_coarse_dists, h->w_visited.as<uint32_t>(), words, nwaves,
+                               h->w_status.as<uint32_t>(), h->w_status.as<uint32_t>() + 1));
+    } else {
+        const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
+        if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
+            return rc;
+        HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
+                              d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
+                              h->w_status.as<uint32_t>() + 1));
+    }
     return IVFHNSW_OK;
 }
 

@@ -86,6 +86,19 @@ __device__ __forceinline__ float l2_ref_order_quad(const float *__restrict__ row
     return r;
 }
 
+// the reference's left-to-right sum of its eight accumulators, held two per lane by a quad (lane t: 2t, 2t+1)
+__device__ __forceinline__ float quad_sum8(float alo, float ahi)
+{
+    float r = __fadd_rn(quad_bcast<0>(alo), quad_bcast<0>(ahi));
+    r = __fadd_rn(r, quad_bcast<1>(alo));
+    r = __fadd_rn(r, quad_bcast<1>(ahi));
+    r = __fadd_rn(r, quad_bcast<2>(alo));
+    r = __fadd_rn(r, quad_bcast<2>(ahi));
+    r = __fadd_rn(r, quad_bcast<3>(alo));
+    r = __fadd_rn(r, quad_bcast<3>(ahi));
+    return r;
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {

@@ -91,6 +91,11 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
                          size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query);
 int coarse_slots_for(int ef);
+// four queries per wavefront (ef <= 256)
+hipError_t launch_coarse4(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
+                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
+                          size_t visited_words_per_slot, int nwaves, uint32_t *status, uint32_t *next_query);
+int coarse4_waves_resident();
 // bits of the device status word
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
