@@ -506,8 +506,6 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
                     efSearch, nprobe);
     if (efSearch > 1024)
         return fail(IVFHNSW_ERR_INVALID, "efSearch %zu > 1024 unsupported on the device", efSearch);
-    if (h->gr.d > 128)
-        return fail(IVFHNSW_ERR_INVALID, "d %d > 128 unsupported by the device walk (SIFT is 128-d, DEEP 96-d)", h->gr.d);
     if (nq == 0)
         return IVFHNSW_OK;
     if (nq > 0x7fffffffull)
