@@ -34,39 +34,34 @@ public:
     void reset() { t0_ = std::chrono::steady_clock::now(); }
 };
 
-template <typename T> void read_variable(std::istream &in, T &v) { in.read(reinterpret_cast<char *>(&v), sizeof(T)); }
-template <typename T> void write_variable(std::ostream &out, const T &v)
+namespace detail {
+// one ".xvecs" record: uint32 dimension, then that many elements of type Disk; `sink(j, value)` receives them
+template <typename Disk, typename Sink> inline void read_record(std::istream &in, size_t want_dim, Sink sink)
 {
-    out.write(reinterpret_cast<const char *>(&v), sizeof(T));
+    uint32_t dim = 0;
+    in.read(reinterpret_cast<char *>(&dim), sizeof(dim));
+    if (dim != want_dim) {
+        std::cout << "file error\n";
+        exit(1);
+    }
+    std::vector<Disk> rec(dim);
+    in.read(reinterpret_cast<char *>(rec.data()), (std::streamsize)dim * sizeof(Disk));
+    for (size_t j = 0; j < dim; j++)
+        sink(j, rec[j]);
 }
+} // namespace detail
 
-/// vector on disk = uint32 element count, then the elements
-template <typename T> void read_vector(std::istream &in, std::vector<T> &vec)
-{
-    uint32_t n = 0;
-    in.read(reinterpret_cast<char *>(&n), sizeof(n));
-    vec.resize(n);
-    in.read(reinterpret_cast<char *>(vec.data()), (std::streamsize)n * sizeof(T));
-}
-template <typename T> void write_vector(std::ostream &out, std::vector<T> &vec)
-{
-    const uint32_t n = (uint32_t)vec.size();
-    out.write(reinterpret_cast<const char *>(&n), sizeof(n));
-    out.write(reinterpret_cast<const char *>(vec.data()), (std::streamsize)n * sizeof(T));
-}
-
-/// n records of "uint32 dim, dim elements" (.fvecs / .ivecs / .bvecs)
+/// n records of "uint32 dim, dim elements" (.fvecs / .ivecs / .bvecs), elements kept as stored
 template <typename T> void readXvec(std::ifstream &in, T *data, const size_t d, const size_t n = 1)
 {
-    for (size_t i = 0; i < n; i++) {
-        uint32_t dim = 0;
-        in.read(reinterpret_cast<char *>(&dim), sizeof(dim));
-        if (dim != d) {
-            std::cout << "file error\n";
-            exit(1);
-        }
-        in.read(reinterpret_cast<char *>(data + i * d), (std::streamsize)d * sizeof(T));
-    }
+    for (size_t i = 0; i < n; i++)
+        detail::read_record<T>(in, d, [&](size_t j, T v) { data[i * d + j] = v; });
+}
+/// same records, elements converted to float (SIFT bytes -> float)
+template <typename T> void readXvecFvec(std::ifstream &in, float *data, const size_t d, const size_t n = 1)
+{
+    for (size_t i = 0; i < n; i++)
+        detail::read_record<T>(in, d, [&](size_t j, T v) { data[i * d + j] = (float)v; });
 }
 template <typename T> void writeXvec(std::ofstream &out, T *data, const size_t d, const size_t n = 1)
 {
@@ -76,21 +71,25 @@ template <typename T> void writeXvec(std::ofstream &out, T *data, const size_t d
         out.write(reinterpret_cast<const char *>(data + i * d), (std::streamsize)d * sizeof(T));
     }
 }
-/// same records, elements converted to float
-template <typename T> void readXvecFvec(std::ifstream &in, float *data, const size_t d, const size_t n = 1)
+
+/// scalars and vectors of the .index files: a vector is a uint32 element count followed by the elements
+template <typename T> void write_variable(std::ostream &out, const T &v)
 {
-    std::vector<T> rec(d);
-    for (size_t i = 0; i < n; i++) {
-        uint32_t dim = 0;
-        in.read(reinterpret_cast<char *>(&dim), sizeof(dim));
-        if (dim != d) {
-            std::cout << "file error\n";
-            exit(1);
-        }
-        in.read(reinterpret_cast<char *>(rec.data()), (std::streamsize)d * sizeof(T));
-        for (size_t j = 0; j < d; j++)
-            data[i * d + j] = (float)rec[j];
-    }
+    out.write(reinterpret_cast<const char *>(&v), sizeof(T));
+}
+template <typename T> void read_variable(std::istream &in, T &v) { in.read(reinterpret_cast<char *>(&v), sizeof(T)); }
+template <typename T> void write_vector(std::ostream &out, std::vector<T> &vec)
+{
+    const uint32_t n = (uint32_t)vec.size();
+    write_variable(out, n);
+    out.write(reinterpret_cast<const char *>(vec.data()), (std::streamsize)n * sizeof(T));
+}
+template <typename T> void read_vector(std::istream &in, std::vector<T> &vec)
+{
+    uint32_t n = 0;
+    read_variable(in, n);
+    vec.resize(n);
+    in.read(reinterpret_cast<char *>(vec.data()), (std::streamsize)n * sizeof(T));
 }
 
 inline bool exists(const char *path)

@@ -29,10 +29,19 @@ template <typename T> void get(std::istream &i, T &v) { i.read(reinterpret_cast<
 } // namespace
 
 HierarchicalNSW::HierarchicalNSW(size_t d, size_t maxelements, size_t M, size_t maxM, size_t efConstruction)
-    : maxelements_(maxelements), cur_element_count(0), efConstruction_(efConstruction), visitedlistpool(nullptr),
-      enterpoint_node(0), dist_calc(0), data_level0_memory_(nullptr), d_(d), data_size_(d * sizeof(float)),
-      offset_data(0), size_data_per_element(0), M_(M), maxM_(maxM), size_links_level0(0), efSearch(efConstruction)
 {
+    efSearch = efConstruction;
+    data_level0_memory_ = nullptr;
+    d_ = d;
+    data_size_ = d * sizeof(float);
+    M_ = M;
+    maxM_ = maxM;
+    efConstruction_ = efConstruction;
+    maxelements_ = maxelements;
+    cur_element_count = 0;
+    enterpoint_node = 0;
+    visitedlistpool = nullptr;
+    dist_calc = 0;
     size_links_level0 = maxM_ * sizeof(idx_t) + sizeof(uint8_t);
     offset_data = size_links_level0;
     size_data_per_element = size_links_level0 + data_size_;
@@ -45,10 +54,14 @@ HierarchicalNSW::HierarchicalNSW(size_t d, size_t maxelements, size_t M, size_t 
 
 HierarchicalNSW::HierarchicalNSW(const std::string &infoLocation, const std::string &dataLocation,
                                  const std::string &edgeLocation)
-    : maxelements_(0), cur_element_count(0), efConstruction_(0), visitedlistpool(nullptr), enterpoint_node(0),
-      dist_calc(0), data_level0_memory_(nullptr), d_(0), data_size_(0), offset_data(0), size_data_per_element(0),
-      M_(0), maxM_(0), size_links_level0(0), efSearch(0)
 {
+    efSearch = 0;
+    data_level0_memory_ = nullptr;
+    size_data_per_element = size_links_level0 = offset_data = data_size_ = d_ = 0;
+    M_ = maxM_ = efConstruction_ = maxelements_ = cur_element_count = 0;
+    enterpoint_node = 0;
+    visitedlistpool = nullptr;
+    dist_calc = 0;
     LoadInfo(infoLocation);
     LoadData(dataLocation);
     LoadEdges(edgeLocation);
