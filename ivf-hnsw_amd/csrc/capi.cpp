@@ -567,9 +567,38 @@ int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k
     return check_status(h);
 }
 
+static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
+                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
+                            int64_t *d_labels, int64_t *d_out_keys);
+
+// Batches beyond kMaxBatch queries are processed in slices so that the per-batch workspace (16 KB of table per
+// query at PQ16, plus the plan) stays bounded; the multi-GPU resolve step needs the whole plan, so it is limited
+// to one slice.
+static const size_t kMaxBatch = 1 << 17;
+
 int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                            int64_t *d_labels, int64_t *d_out_keys)
+{
+    if (nq <= kMaxBatch || !h || !p)
+        return search_dev_chunk(h, nq, k, d_queries, d_coarse_ids, d_coarse_dists, p, d_distances, d_labels, d_out_keys);
+    if (d_out_keys)
+        return fail(IVFHNSW_ERR_INVALID, "sharded search (out_keys) is limited to %zu queries per call", kMaxBatch);
+    const size_t d = (size_t)h->t.d;
+    for (size_t q0 = 0; q0 < nq; q0 += kMaxBatch) {
+        const size_t n = std::min(kMaxBatch, nq - q0);
+        int rc = search_dev_chunk(h, n, k, d_queries + q0 * d, d_coarse_ids ? d_coarse_ids + q0 * p->nprobe : nullptr,
+                                  d_coarse_dists ? d_coarse_dists + q0 * p->nprobe : nullptr, p, d_distances + q0 * k,
+                                  d_labels + q0 * k, nullptr);
+        if (rc)
+            return rc;
+    }
+    return IVFHNSW_OK;
+}
+
+static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
+                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
+                            int64_t *d_labels, int64_t *d_out_keys)
 {
     int rc = bind(h);
     if (rc)
