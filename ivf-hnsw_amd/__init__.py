@@ -193,7 +193,8 @@ class GpuIndex:
     def search(self, queries, k, nprobe, max_codes, coarse_ids=None, coarse_dists=None, efSearch=0,
                do_pruning=False):
         """Host arrays in, host arrays out (ivfhnsw_gpu_search)."""
-        q = _np(queries, np.float32).reshape(-1, self.d)
+        q = _np(queries, np.float32)
+        q = q.reshape(-1, self.d or q.shape[-1])  # before any upload the library itself refuses the call
         nq = q.shape[0]
         cid = None if coarse_ids is None else _np(coarse_ids, np.uint32).reshape(nq, nprobe)
         cd = None if coarse_dists is None else _np(coarse_dists, np.float32).reshape(nq, nprobe)
