@@ -100,6 +100,8 @@ typedef struct ivfhnsw_search_params {
     size_t max_codes;
     size_t efSearch;
     int do_pruning;
+    int heap_order; /* k > 1 only: 0 = results ascending by (distance, scan position); 1 = exactly the array
+                       faiss's max-heap leaves behind (IndexIVF_HNSW.cpp:265,285-288), slot 0 = current worst */
 } ivfhnsw_search_params;
 
 /* IndexIVF_HNSW::search / IndexIVF_HNSW_Grouping::search (IndexIVF_HNSW.cpp:234-296,
@@ -110,10 +112,12 @@ typedef struct ivfhnsw_search_params {
  * 0xffffffff are skipped.  Pass NULL for both to run the HNSW walk (hnswalg.cpp:48-109,227-234) on
  * the device; that needs upload_quantizer and efSearch >= nprobe.
  *
- * Results: distances[nq*k], labels[nq*k] (int64, the reference's `long`), ascending by
- * (distance, scan position); unfilled slots hold FLT_MAX / -1 as after faiss::maxheap_heapify.
- * For k = 1 (every preset of the reference) this is exactly the reference's output; for k > 1 it is
- * the same set, sorted, where the reference leaves heap-array order. */
+ * Results: distances[nq*k], labels[nq*k] (int64, the reference's `long`); unfilled slots hold FLT_MAX / -1 as
+ * after faiss::maxheap_heapify.  For k = 1 (every preset of the reference) this is exactly the reference's
+ * output.  For k > 1 the same set is returned either ascending by (distance, scan position)
+ * (params->heap_order = 0) or, with heap_order = 1, in exactly the heap-array order the reference leaves: the
+ * device replays faiss's pop/push over a superset of the admitted codes in scan order, which yields the same
+ * heap because a code that fails `dist < distances[0]` leaves the heap untouched. */
 int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries, const uint32_t *coarse_ids,
                        const float *coarse_dists, const ivfhnsw_search_params *params, float *distances,
                        int64_t *labels);

@@ -38,7 +38,7 @@ class IvfDesc(C.Structure):
 
 class SearchParams(C.Structure):
     _fields_ = [("nprobe", C.c_size_t), ("max_codes", C.c_size_t), ("efSearch", C.c_size_t),
-                ("do_pruning", C.c_int)]
+                ("do_pruning", C.c_int), ("heap_order", C.c_int)]
 
 
 class IvfHnswError(RuntimeError):
@@ -187,11 +187,11 @@ class GpuIndex:
 
     # ---- search --------------------------------------------------------------------------------
     @staticmethod
-    def _params(nprobe, max_codes, efSearch, do_pruning):
-        return SearchParams(nprobe, max_codes, efSearch, 1 if do_pruning else 0)
+    def _params(nprobe, max_codes, efSearch, do_pruning, heap_order=False):
+        return SearchParams(nprobe, max_codes, efSearch, 1 if do_pruning else 0, 1 if heap_order else 0)
 
     def search(self, queries, k, nprobe, max_codes, coarse_ids=None, coarse_dists=None, efSearch=0,
-               do_pruning=False):
+               do_pruning=False, heap_order=False):
         """Host arrays in, host arrays out (ivfhnsw_gpu_search)."""
         q = _np(queries, np.float32)
         q = q.reshape(-1, self.d or q.shape[-1])  # before any upload the library itself refuses the call
@@ -200,7 +200,7 @@ class GpuIndex:
         cd = None if coarse_dists is None else _np(coarse_dists, np.float32).reshape(nq, nprobe)
         dist = np.empty((nq, k), np.float32)
         lab = np.empty((nq, k), np.int64)
-        p = self._params(nprobe, max_codes, efSearch, do_pruning)
+        p = self._params(nprobe, max_codes, efSearch, do_pruning, heap_order)
         _check(lib().ivfhnsw_gpu_search(self._h, nq, k, _ptr(q), _ptr(cid), _ptr(cd), C.byref(p), _ptr(dist),
                                         _ptr(lab)))
         return dist, lab

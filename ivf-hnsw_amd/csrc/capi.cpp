@@ -89,7 +89,8 @@ struct ivfhnsw_gpu {
     bool has_graph = false;
 
     // per-batch workspace
-    DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status;
+    DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
+        w_slen;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
 
@@ -171,6 +172,9 @@ int drain_events(ivfhnsw_gpu *h)
     return IVFHNSW_OK;
 }
 
+// candidate-stream entries per query kept for the heap-order replay (k > 1)
+static const uint32_t kHeapStreamCap = 8192;
+
 // After a stream sync: did any kernel flag something it could not represent?
 int check_status(ivfhnsw_gpu *h)
 {
@@ -182,6 +186,9 @@ int check_status(ivfhnsw_gpu *h)
     if (st & kStatusHnswTieOverflow)
         return fail(IVFHNSW_ERR_STATE, "HNSW walk: more than 64 candidates tie exactly with the efSearch-th "
                                        "distance; results of this batch are invalid");
+    if (st & kStatusTopkStreamOverflow)
+        return fail(IVFHNSW_ERR_STATE, "heap-order top-k: candidate stream of a query exceeded %u entries; use "
+                                       "heap_order = 0 for this k / max_codes", kHeapStreamCap);
     return fail(IVFHNSW_ERR_STATE, "device status 0x%x", st);
 }
 
@@ -273,7 +280,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 1; }
+int ivfhnsw_gpu_abi_version(void) { return 2; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
@@ -323,7 +330,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     if (h->own_stream)
@@ -574,12 +581,13 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
 // Batches beyond kMaxBatch queries are processed in slices so that the per-batch workspace (16 KB of table per
 // query at PQ16, plus the plan) stays bounded; the multi-GPU resolve step needs the whole plan, so it is limited
 // to one slice.
-static const size_t kMaxBatch = 1 << 17;
+static const size_t kMaxBatchAll = 1 << 17;
 
 int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                            int64_t *d_labels, int64_t *d_out_keys)
 {
+    const size_t kMaxBatch = (p && p->heap_order && k > 1) ? kMaxBatchAll / 8 : kMaxBatchAll;
     if (nq <= kMaxBatch || !h || !p)
         return search_dev_chunk(h, nq, k, d_queries, d_coarse_ids, d_coarse_dists, p, d_distances, d_labels, d_out_keys);
     if (d_out_keys)
@@ -684,6 +692,15 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq));
     }
     // 5. scan (IndexIVF_HNSW.cpp:282-289)
+    const bool heap = p->heap_order && k > 1;
+    if (heap) {
+        if (d_out_keys)
+            return fail(IVFHNSW_ERR_INVALID, "heap_order is not available together with out_keys (sharded merge)");
+        if ((rc = h->w_stream.ensure(nq * (size_t)kHeapStreamCap * sizeof(uint64_t))))
+            return rc;
+        if ((rc = h->w_slen.ensure(nq * sizeof(uint32_t))))
+            return rc;
+    }
     {
         // small batches: split each query over several workgroups so the chip still fills
         int nsplit = 1;
@@ -691,13 +708,20 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
             nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
         StageScope sc(h, IVFHNSW_STAGE_SCAN);
         HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
-                            h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>()));
+                            h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
+                            heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
+                            heap ? kHeapStreamCap : 0));
     }
     // 6. select
     {
         StageScope sc(h, IVFHNSW_STAGE_SELECT);
-        HIP_TRY(launch_select(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
-                              h->w_keys.as<uint64_t>(), (int)nq, (int)k, d_distances, d_labels, d_out_keys));
+        if (heap)
+            HIP_TRY(launch_heap_replay(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
+                                       h->w_stream.as<uint64_t>(), h->w_slen.as<uint32_t>(), kHeapStreamCap, (int)nq,
+                                       (int)k, d_distances, d_labels, h->w_status.as<uint32_t>()));
+        else
+            HIP_TRY(launch_select(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
+                                  h->w_keys.as<uint64_t>(), (int)nq, (int)k, d_distances, d_labels, d_out_keys));
     }
     h->last_nq = (int)nq;
     h->last_max_seg = max_seg;
@@ -828,7 +852,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

@@ -67,21 +67,9 @@ void IndexIVF_HNSW_Grouping::search_batch(size_t nq, size_t k, const float *x, f
     p.max_codes = max_codes;
     p.efSearch = quantizer->efSearch;
     p.do_pruning = do_pruning ? 1 : 0;
+    p.heap_order = 1;
     if (ivfhnsw_gpu_search(gpu_, nq, k, x, nullptr, nullptr, &p, distances, reinterpret_cast<int64_t *>(labels)))
         throw std::runtime_error(std::string("ivfhnsw_gpu_search: ") + ivfhnsw_gpu_last_error());
-    if (k > 1) {
-        // ascending -> a valid faiss max-heap array (see IndexIVF_HNSW::search_batch)
-        for (size_t i = 0; i < nq; i++) {
-            std::vector<float> dv(distances + i * k, distances + (i + 1) * k);
-            std::vector<long> lv(labels + i * k, labels + (i + 1) * k);
-            faiss::maxheap_heapify(k, distances + i * k, labels + i * k);
-            for (size_t j = 0; j < k; j++)
-                if (lv[j] >= 0) {
-                    faiss::maxheap_pop(k, distances + i * k, labels + i * k);
-                    faiss::maxheap_push(k, distances + i * k, labels + i * k, dv[j], lv[j]);
-                }
-        }
-    }
 }
 
 void IndexIVF_HNSW_Grouping::search(size_t k, const float *x, float *distances, long *labels)

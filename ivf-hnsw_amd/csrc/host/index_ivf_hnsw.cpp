@@ -20,29 +20,6 @@ namespace {
     throw std::runtime_error(std::string(what) + ": " + ivfhnsw_gpu_last_error());
 }
 
-// the C ABI returns results ascending; the reference leaves them in faiss max-heap array order.  Re-insert so
-// that callers relying on the heap property (distances[0] = current worst) keep working.  For k = 1 this is
-// the identity.
-void to_heap_order(size_t k, float *distances, long *labels)
-{
-    if (k < 2)
-        return;
-    std::vector<float> dv(distances, distances + k);
-    std::vector<long> lv(labels, labels + k);
-    faiss::maxheap_heapify(k, distances, labels);
-    size_t filled = 0;
-    for (size_t i = 0; i < k; i++)
-        if (lv[i] >= 0)
-            filled++;
-    // empty slots (FLT_MAX, -1) must sit where a heap of `filled` pushes would leave them: build by pop/push
-    for (size_t i = 0; i < k; i++) {
-        if (lv[i] < 0)
-            continue;
-        faiss::maxheap_pop(k, distances, labels);
-        faiss::maxheap_push(k, distances, labels, dv[i], lv[i]);
-    }
-}
-
 } // namespace
 
 IndexIVF_HNSW::IndexIVF_HNSW(size_t dim, size_t ncentroids, size_t bytes_per_code, size_t nbits_per_idx,
@@ -198,10 +175,9 @@ void IndexIVF_HNSW::search_batch(size_t nq, size_t k, const float *x, float *dis
     p.max_codes = max_codes;
     p.efSearch = quantizer->efSearch;
     p.do_pruning = 0;
+    p.heap_order = 1; // k > 1: the array faiss's max-heap leaves, as the reference returns it
     if (ivfhnsw_gpu_search(gpu_, nq, k, x, nullptr, nullptr, &p, distances, reinterpret_cast<int64_t *>(labels)))
         gpu_fail("ivfhnsw_gpu_search");
-    for (size_t i = 0; i < nq; i++)
-        to_heap_order(k, distances + i * k, labels + i * k);
 }
 
 void IndexIVF_HNSW::search(size_t k, const float *x, float *distances, long *labels)
@@ -233,7 +209,7 @@ IndexIVF_HNSW::idx_t IndexIVF_HNSW::search_enn(const float *x, float *distances,
     if (ivfhnsw_gpu_coarse(gpu_, 1, q, 1, quantizer->efSearch ? quantizer->efSearch : 1, &cid, &cd))
         gpu_fail("ivfhnsw_gpu_coarse");
     std::cout << "Get centroid in ENN: " << cid << std::endl;
-    ivfhnsw_search_params p = {1, max_codes, quantizer->efSearch, 0};
+    ivfhnsw_search_params p = {1, max_codes, quantizer->efSearch, 0, 1};
     if (ivfhnsw_gpu_search(gpu_, 1, 1, x, &cid, &cd, &p, distances, reinterpret_cast<int64_t *>(labels)))
         gpu_fail("ivfhnsw_gpu_search");
     return cid;
@@ -243,11 +219,10 @@ void IndexIVF_HNSW::search2(size_t k, const float *x, float *distances, long *la
                             idx_t *centroid_idxs)
 {
     ensure_device();
-    ivfhnsw_search_params p = {nprobe, max_codes, quantizer->efSearch, 0};
+    ivfhnsw_search_params p = {nprobe, max_codes, quantizer->efSearch, 0, 1};
     if (ivfhnsw_gpu_search(gpu_, 1, k, x, centroid_idxs, query_centroid_dists, &p, distances,
                            reinterpret_cast<int64_t *>(labels)))
         gpu_fail("ivfhnsw_gpu_search");
-    to_heap_order(k, distances, labels);
 }
 
 void IndexIVF_HNSW::search2m(size_t k, const float *x, float *distances[], long *labels[],
@@ -256,11 +231,10 @@ void IndexIVF_HNSW::search2m(size_t k, const float *x, float *distances[], long 
     // one result heap per probe (the reference's variant is racy; this one is well defined): probe i alone
     ensure_device();
     for (size_t i = 0; i < nprobe; i++) {
-        ivfhnsw_search_params p = {1, (size_t)-1, quantizer->efSearch, 0};
+        ivfhnsw_search_params p = {1, (size_t)-1, quantizer->efSearch, 0, 1};
         if (ivfhnsw_gpu_search(gpu_, 1, k, x, centroid_idxs + i, query_centroid_dists + i, &p, distances[i],
                                reinterpret_cast<int64_t *>(labels[i])))
             gpu_fail("ivfhnsw_gpu_search");
-        to_heap_order(k, distances[i], labels[i]);
     }
 }
 

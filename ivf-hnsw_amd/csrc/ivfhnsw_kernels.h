@@ -79,7 +79,12 @@ hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTa
                                 PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *qsd_scratch);
 // the ADC loop (IndexIVF_HNSW.cpp:282-289 / IndexIVF_HNSW_Grouping.cpp:321-333)
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
-                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys);
+                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys,
+                       uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0);
+// k > 1 in faiss heap-array order: sequential replay of the top-k kernel's candidate stream
+hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                              const uint64_t *stream, const uint32_t *stream_len, uint32_t stream_cap, int nq, int k,
+                              float *dist, int64_t *labels, uint32_t *status);
 // keys -> (distance, label) through the plan; also emits signed-orderable keys when out_keys != null
 hipError_t launch_select(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
                          const uint64_t *keys, int nq, int k, float *dist, int64_t *labels, int64_t *out_keys);
@@ -98,6 +103,7 @@ hipError_t launch_coarse4(hipStream_t s, const GraphTables &g, const float *xq, 
 int coarse4_waves_resident();
 // bits of the device status word
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
+constexpr uint32_t kStatusTopkStreamOverflow = 2u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);

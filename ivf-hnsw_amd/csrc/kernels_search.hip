@@ -486,15 +486,17 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
 }
 
 hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
-                            const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int k, uint64_t *keys);
+                            const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int k, uint64_t *keys,
+                            uint64_t *stream, uint32_t *stream_len, uint32_t stream_cap);
 
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
-                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys)
+                       const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys, uint64_t *stream,
+                       uint32_t *stream_len, uint32_t stream_cap)
 {
     if (nq == 0)
         return hipSuccess;
     if (k != 1)
-        return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys);
+        return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys, stream, stream_len, stream_cap);
     switch (t.M) {
     case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
     case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
                                                         const float *__restrict__ norm_table,
                                                         const Seg *__restrict__ segs, const uint32_t *__restrict__ lpos,
                                                         const PlanHdr *__restrict__ hdr, int max_seg, int k,
-                                                        unsigned long long *__restrict__ keys)
+                                                        unsigned long long *__restrict__ keys,
+                                                        unsigned long long *__restrict__ stream,
+                                                        uint32_t *__restrict__ stream_len, uint32_t stream_cap)
 {
     __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
     __shared__ float s_norm[256];
@@ -57,12 +59,17 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
     __shared__ unsigned long long s_buf[TK_N];
     __shared__ uint32_t s_ncand;
     __shared__ unsigned long long s_T;
+    __shared__ uint32_t s_wcnt[TK_U][4]; // candidates per (unroll step, wave) of the current iteration
+    __shared__ uint32_t s_slen;          // length of this query's candidate stream so far
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
     const PlanHdr h = hdr[q];
-    if (h.total == 0)
+    if (h.total == 0) {
+        if (stream_len && tid == 0)
+            stream_len[q] = 0;
         return; // keys were reset by the plan kernel
+    }
     {
         const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
         float4 *dst = reinterpret_cast<float4 *>(s_lut);
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
             s_buf[i] = ~0ull;
         if (tid == 0) {
             s_ncand = 0;
+            s_slen = 0;
             s_T = kKeyInit;
         }
     }
@@ -115,9 +123,13 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
             if (fill > TK_N - TK_KCAP - 256 * TK_U)
                 flush();
             const unsigned long long T = s_T;
+            unsigned long long key[TK_U];
+            bool pass[TK_U];
 #pragma unroll
             for (int u = 0; u < TK_U; u++) {
                 const uint32_t p = base + u * 256 + tid;
+                pass[u] = false;
+                key[u] = 0;
                 if (p < ch) {
                     uint32_t a = s, b = cn - 1;
                     while (a < b) {
@@ -138,13 +150,52 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
                     const float tt = __fadd_rn(sg.cterm, s_norm[nb]);
                     const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
                     if (dist < FLT_MAX) {
-                        const unsigned long long key =
-                            ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (sg.vpos + off);
-                        if (key < T) {
-                            const uint32_t slot = atomicAdd(&s_ncand, 1u);
-                            s_buf[TK_KCAP + slot] = key;
-                        }
+                        key[u] = ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (sg.vpos + off);
+                        pass[u] = key[u] < T;
                     }
+                }
+            }
+            // Append the candidates IN SCAN ORDER (position = unroll step, then wave, then lane): the buffer is
+            // then a stream a sequential consumer can replay (heap-order output, below).
+            unsigned long long bal[TK_U];
+#pragma unroll
+            for (int u = 0; u < TK_U; u++) {
+                bal[u] = __ballot(pass[u]);
+                if ((tid & 63) == 0)
+                    s_wcnt[u][tid >> 6] = (uint32_t)__popcll(bal[u]);
+            }
+            __syncthreads();
+            {
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (int u = 0; u < TK_U; u++)
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; w2++) {
+                        const uint32_t c = s_wcnt[u][w2];
+                        total += c;
+                        (void)before;
+                    }
+                const uint32_t nc0 = s_ncand, sl0 = s_slen;
+#pragma unroll
+                for (int u = 0; u < TK_U; u++) {
+                    uint32_t off = 0;
+#pragma unroll
+                    for (int u2 = 0; u2 < TK_U; u2++)
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; w2++)
+                            if (u2 < u || (u2 == u && w2 < (tid >> 6)))
+                                off += s_wcnt[u2][w2];
+                    if (pass[u]) {
+                        const uint32_t pos = off + (uint32_t)__popcll(bal[u] & ((1ull << (tid & 63)) - 1ull));
+                        s_buf[TK_KCAP + nc0 + pos] = key[u];
+                        if (stream && sl0 + pos < stream_cap)
+                            stream[(size_t)q * stream_cap + sl0 + pos] = key[u];
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    s_ncand = nc0 + total;
+                    s_slen = sl0 + total;
                 }
             }
             __syncthreads();
@@ -155,10 +206,111 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
         const unsigned long long v = s_buf[j];
         keys[(size_t)q * k + j] = v < kKeyInit ? v : kKeyInit;
     }
+    if (stream_len && tid == 0)
+        stream_len[q] = s_slen; // > stream_cap: the stream was truncated (the consumer reports it)
+}
+
+// ---------------------------------------------------------------------------------------------
+// faiss heap-array order for k > 1 (IndexIVF_HNSW.cpp:265,285-288).  The reference pushes a code iff
+// dist < distances[0] at that moment; a code that fails the test leaves the heap untouched.  Replaying the same
+// pop/push over ANY superset of the admitted codes, in scan order, therefore reproduces the heap exactly -- and
+// the candidate stream above is such a superset (its filter threshold is never below the heap's current
+// maximum).  One thread per query; faiss Heap.h semantics (1-based binary max-heap on values only).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void heap_replace_top(int k, float *val, long long *ids, float nv, long long nid)
+{
+    // maxheap_pop followed by maxheap_push, as the reference calls them
+    float *v = val - 1;
+    long long *id = ids - 1;
+    {
+        const float last = v[k];
+        int hole = 1;
+        for (;;) {
+            const int l = hole * 2, r = l + 1;
+            if (l > k)
+                break;
+            const int big = (r == k + 1 || v[l] > v[r]) ? l : r;
+            if (last > v[big])
+                break;
+            v[hole] = v[big];
+            id[hole] = id[big];
+            hole = big;
+        }
+        v[hole] = v[k];
+        id[hole] = id[k];
+    }
+    {
+        int hole = k;
+        while (hole > 1) {
+            const int parent = hole / 2;
+            if (!(nv > v[parent]))
+                break;
+            v[hole] = v[parent];
+            id[hole] = id[parent];
+            hole = parent;
+        }
+        v[hole] = nv;
+        id[hole] = nid;
+    }
+}
+
+__global__ void heap_replay_kernel(IvfTables t, const Seg *__restrict__ segs, const PlanHdr *__restrict__ hdr, int max_seg,
+                                   const unsigned long long *__restrict__ stream, const uint32_t *__restrict__ stream_len,
+                                   uint32_t stream_cap, int nq, int k, float *__restrict__ dist,
+                                   long long *__restrict__ labels, uint32_t *__restrict__ status)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq)
+        return;
+    float *val = dist + (size_t)q * k;
+    long long *ids = labels + (size_t)q * k;
+    for (int j = 0; j < k; j++) { // maxheap_heapify
+        val[j] = FLT_MAX;
+        ids[j] = -1;
+    }
+    const uint32_t len = stream_len[q];
+    if (len > stream_cap) {
+        atomicOr(status, kStatusTopkStreamOverflow);
+        return;
+    }
+    const Seg *sq = segs + (size_t)q * max_seg;
+    const uint32_t nseg = hdr[q].nseg;
+    const unsigned long long *st = stream + (size_t)q * stream_cap;
+    for (uint32_t i = 0; i < len; i++) {
+        const unsigned long long key = st[i];
+        const float d = orderable_f32((uint32_t)(key >> 32));
+        if (!(d < val[0]))
+            continue;
+        // label of scan position vpos (segments ascend in vpos)
+        const uint32_t vpos = (uint32_t)key;
+        uint32_t a = 0, b = nseg - 1;
+        while (a < b) {
+            const uint32_t mid = (a + b + 1) >> 1;
+            if (sq[mid].vpos <= vpos)
+                a = mid;
+            else
+                b = mid - 1;
+        }
+        const Seg sg = sq[a];
+        heap_replace_top(k, val, ids, d, (long long)t.ids[sg.start + (vpos - sg.vpos)]);
+    }
+}
+
+hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
+                              const uint64_t *stream, const uint32_t *stream_len, uint32_t stream_cap, int nq, int k,
+                              float *dist, int64_t *labels, uint32_t *status)
+{
+    if (nq == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(heap_replay_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, t, segs, hdr, max_seg,
+                       reinterpret_cast<const unsigned long long *>(stream), stream_len, stream_cap, nq, k, dist,
+                       reinterpret_cast<long long *>(labels), status);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
-                            const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int k, uint64_t *keys)
+                            const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int k, uint64_t *keys,
+                            uint64_t *stream, uint32_t *stream_len, uint32_t stream_cap)
 {
     if (k < 1 || k > TK_KCAP)
         return hipErrorInvalidValue;
@@ -166,7 +318,7 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
 #define IVFHNSW_TOPK(CS)                                                                                              \
     hipLaunchKernelGGL((scan_topk_kernel<CS>), grid, block, 0, s, t.codes, t.norm_codes, luts, t.norm_table, segs, lpos, \
-                       hdr, max_seg, k, k64)
+                       hdr, max_seg, k, k64, reinterpret_cast<unsigned long long *>(stream), stream_len, stream_cap)
     switch (t.M) {
     case 4: IVFHNSW_TOPK(4); break;
     case 8: IVFHNSW_TOPK(8); break;
