@@ -92,6 +92,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     n_total, nc, d, M, nprobe, max_codes, ef, nq = WORKLOADS[args.workload]
+    if os.environ.get("IVFHNSW_BENCH_MAX_CODES"):   # experiment knob: longer / shorter scans per query
+        max_codes = int(os.environ["IVFHNSW_BENCH_MAX_CODES"])
     scale = args.scale if args.scale > 0 else world
     n_total, nc, nq = n_total * scale, nc * scale, nq * scale
     if n_total >= 2 ** 32:
