@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivfhnsw_hip.so")
+LIB_PATH = os.environ.get("IVFHNSW_HIP_LIB") or os.path.join(_HERE, "libivfhnsw_hip.so")  # override: A/B runs of two builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4
 STAGES = ("opq", "coarse", "lut", "plan", "scan", "select")

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -84,7 +85,7 @@ struct ivfhnsw_gpu {
     DevBuf g_alpha, g_nn, g_sizes, g_inter;
     GroupTables g{};
     bool has_group = false;
-    DevBuf q_counts, q_links, q_vectors;
+    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows;
     GraphTables gr{};
     bool has_graph = false;
 
@@ -328,7 +329,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
@@ -464,6 +465,86 @@ int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alpha
     return IVFHNSW_OK;
 }
 
+// The walk's exact rejection filter (kernels_hnsw.hip): one byte per component, x ~ lo + step * byte with one
+// (lo, step) for the whole table, and the largest row error ||x - (lo + step*byte)|| in units of step, rounded
+// up.  Tables with non-finite values, a single value or d > 2048 run without the filter (always exact, only
+// slower); IVFHNSW_WALK_PREFILTER=0 turns it off for A/B runs.
+static int build_byte_rows(ivfhnsw_gpu *h, size_t n, size_t d, const float *vectors)
+{
+    static const bool off = [] {
+        const char *e = getenv("IVFHNSW_WALK_PREFILTER");
+        return e && atoi(e) == 0;
+    }();
+    if (off || d > 2048)
+        return IVFHNSW_OK;
+    float lo = vectors[0], hi = vectors[0];
+    bool finite = true;
+    for (size_t i = 0; i < n * d; i++) {
+        const float v = vectors[i];
+        finite &= std::isfinite(v);
+        lo = std::min(lo, v);
+        hi = std::max(hi, v);
+    }
+    const float step = (float)(((double)hi - (double)lo) / 255.0);
+    if (!finite || !(step > 0.f) || !std::isfinite(step) || !std::isfinite(1.f / step))
+        return IVFHNSW_OK;
+    std::vector<uint8_t> rows(n * d);
+    double worst = 0.0;
+    for (size_t r = 0; r < n; r++) {
+        double e2 = 0.0;
+        for (size_t j = 0; j < d; j++) {
+            const double x = vectors[r * d + j];
+            double c = std::nearbyint((x - (double)lo) / (double)step);
+            c = std::min(255.0, std::max(0.0, c));
+            rows[r * d + j] = (uint8_t)c;
+            const double e = x - ((double)lo + (double)step * c);
+            e2 += e * e;
+        }
+        worst = std::max(worst, e2);
+    }
+    const double errc = std::sqrt(worst) / (double)step * (1.0 + 1e-6) + 1e-6;
+    float errc_f = (float)errc;
+    if ((double)errc_f < errc)
+        errc_f = std::nextafter(errc_f, INFINITY);
+    int rc = upload(h->q_qrows, rows.data(), n * d);
+    if (rc)
+        return rc;
+    h->gr.qrows = h->q_qrows.as<uint8_t>();
+    h->gr.q_lo = lo;
+    h->gr.q_step = step;
+    h->gr.q_errc = errc_f;
+    return IVFHNSW_OK;
+}
+
+// Second copy of the byte rows in walk order (GraphTables::nbrows): 128 B per link, so n * maxM * 128 bytes --
+// 4 GiB for the reference's 993127-centroid, maxM 32 quantizer.  Skipped (the walk then gathers from qrows)
+// for d > 128, above IVFHNSW_WALK_NBROWS_GIB (default 48) and with IVFHNSW_WALK_PREFILTER=1.
+static int build_neighbour_rows(ivfhnsw_gpu *h)
+{
+    static const int mode = [] {
+        const char *e = getenv("IVFHNSW_WALK_PREFILTER");
+        return e ? atoi(e) : 2;
+    }();
+    static const double cap_gib = [] {
+        const char *e = getenv("IVFHNSW_WALK_NBROWS_GIB");
+        return e ? atof(e) : 48.0;
+    }();
+    if (!h->gr.qrows || mode != 2 || h->gr.d > 128)
+        return IVFHNSW_OK;
+    const int nb_rows = (h->gr.maxM + 31) & ~31;
+    const size_t bytes = (size_t)h->gr.n * nb_rows * 128;
+    if ((double)bytes > cap_gib * 1073741824.0)
+        return IVFHNSW_OK;
+    int rc = h->q_nbrows.ensure(bytes);
+    if (rc)
+        return rc;
+    HIP_TRY(launch_build_nbrows(h->stream, h->gr, h->q_nbrows.as<uint8_t>(), nb_rows));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->gr.nbrows = h->q_nbrows.as<uint8_t>();
+    h->gr.nb_rows = nb_rows;
+    return IVFHNSW_OK;
+}
+
 int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
                                  const uint8_t *link_counts, const uint32_t *links, const float *vectors)
 {
@@ -496,6 +577,16 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     h->gr.counts = h->q_counts.as<uint8_t>();
     h->gr.links = h->q_links.as<uint32_t>();
     h->gr.vectors = h->q_vectors.as<float>();
+    h->gr.qrows = nullptr;
+    h->gr.nbrows = nullptr;
+    h->gr.nb_rows = 0;
+    h->gr.q_lo = 0.f;
+    h->gr.q_step = 1.f;
+    h->gr.q_errc = 0.f;
+    if ((rc = build_byte_rows(h, n, d, vectors)))
+        return rc;
+    if ((rc = build_neighbour_rows(h)))
+        return rc;
     h->has_graph = true;
     return IVFHNSW_OK;
 }
@@ -851,7 +942,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

@@ -62,6 +62,15 @@ struct GraphTables {
     const uint8_t *counts;
     const uint32_t *links;   // [n][maxM]
     const float *vectors;    // [n][d]
+    // Exact rejection filter of the walk (DESIGN.md "coarse walk"): every row once more as d bytes,
+    // x ~ q_lo + q_step * byte, with q_errc >= max_row ||x - (q_lo + q_step*byte)|| / q_step.  NULL = filter off.
+    const uint8_t *qrows;    // [n][d]
+    float q_lo, q_step, q_errc;
+    // The same bytes once more, laid out for the walk (d <= 128): node i carries the byte rows of its own
+    // neighbours, [n][nb_rows][128] with nb_rows = maxM rounded up to 32, zero padded.  One contiguous
+    // nb_rows*128-byte read per expansion, issued together with the link list.  NULL = gather from qrows.
+    const uint8_t *nbrows;
+    int nb_rows;
 };
 
 // y[q][i] = fmaf chain over k of A[i][k] * x[q][k]  (IndexIVF_HNSW.cpp:240)
@@ -105,6 +114,8 @@ int coarse4_waves_resident();
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
 constexpr uint32_t kStatusTopkStreamOverflow = 2u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
+// nbrows[i][j] = qrows[links[i][j]] for j < counts[i], zero otherwise (GraphTables::nbrows)
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows);
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
 hipError_t launch_fill_lists(hipStream_t s, const IvfTables &t, uint8_t *codes, uint8_t *norm_codes, uint32_t *ids,

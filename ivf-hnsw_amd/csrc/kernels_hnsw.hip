@@ -27,6 +27,7 @@
 #include "device_common.h"
 
 #include <float.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ivfhnsw_gpu_impl {
@@ -144,7 +145,9 @@ template <int NCH> struct RSet {
 // Why: one returning global atomicOr per neighbour on bitmaps that do not fit L2 was the walk's largest cost
 // (19.6 M scattered atomics per 10 k queries, ~1 ms; MI355X guide: scattered atomics run ~17x below the
 // coalesced rate).
-constexpr int kVisBuckets = 1024;
+// The bucket count follows the occupancy the kernel is built for (MINW waves per SIMD, 4 * MINW per CU sharing
+// 160 KB of LDS): 8 KB of buckets at 4, 6 KB at 5, 5 KB at 6, 3 KB at 8.
+constexpr int vis_buckets(int minw) { return minw <= 4 ? 1024 : minw == 5 ? 768 : minw <= 7 ? 640 : 384; }
 
 // TAGW = bits per tag: 8 (8 tags per bucket, graphs up to 255 * 1024 nodes), 12 (5 per bucket, up to 4095 * 1024),
 // 16 (4 per bucket, up to 65535 * 1024); 0 = no LDS set, global bitmap only.  Fields are scanned SWAR-style:
@@ -160,14 +163,14 @@ template <int TAGW> struct VisFields {
     }
 };
 
-template <int TAGW>
+template <int TAGW, int NB>
 __device__ __forceinline__ bool visit_test_and_set(uint32_t id, unsigned long long *vt, uint32_t *bm, bool &used_bitmap)
 {
     if constexpr (TAGW != 0) {
         constexpr unsigned long long kOnes = VisFields<TAGW>::ones();
         constexpr unsigned long long kHighs = kOnes << (TAGW - 1);
-        const uint32_t b = id & (kVisBuckets - 1);
-        const unsigned long long tag = (unsigned long long)((id / kVisBuckets) + 1);
+        const uint32_t b = id % (uint32_t)NB; // NB is a constant: multiply and shift
+        const unsigned long long tag = (unsigned long long)((id / (uint32_t)NB) + 1);
         for (;;) {
             const unsigned long long old = vt[b];
             const unsigned long long x = old ^ (tag * kOnes);
@@ -188,20 +191,79 @@ __device__ __forceinline__ bool visit_test_and_set(uint32_t id, unsigned long lo
     return !(atomicOr(&bm[id >> 5], bit) & bit);
 }
 
-template <int NCH, int MINW, int TAGW>
+// sum over half of a byte row (16-byte chunks h, h+2, ...) of (q'[i] - byte[i])^2; the pair of lanes adds up
+__device__ __forceinline__ float byte_row_dist_half(const uint8_t *row, const float *sqp, int d, int h)
+{
+    const uint4 *r4 = reinterpret_cast<const uint4 *>(row);
+    const int nchunk = d >> 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int j0 = h; j0 < nchunk; j0 += 8) {
+        // four chunks per lane in flight (a 128-byte row in one round trip), then the arithmetic
+        uint4 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            w[i] = j0 + 2 * i < nchunk ? r4[j0 + 2 * i] : make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (j0 + 2 * i < nchunk) {
+                const float4 *qq = reinterpret_cast<const float4 *>(sqp + 16 * (j0 + 2 * i));
+                const uint32_t ws[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float4 qv = qq[c];
+                    const float t0 = qv.x - (float)(ws[c] & 0xffu);
+                    const float t1 = qv.y - (float)((ws[c] >> 8) & 0xffu);
+                    const float t2 = qv.z - (float)((ws[c] >> 16) & 0xffu);
+                    const float t3 = qv.w - (float)(ws[c] >> 24);
+                    a0 = fmaf(t0, t0, a0);
+                    a1 = fmaf(t1, t1, a1);
+                    a2 = fmaf(t2, t2, a2);
+                    a3 = fmaf(t3, t3, a3);
+                }
+            }
+        }
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
+// STAMPS: diagnostic build only (IVFHNSW_WALK_STAMPS=1): s_memtime at segment boundaries, per-segment cycle sums
+// added to stamp_out[0..5] (selection, links+visited, distances, admissions, per-query prologue, expansions).
+__device__ __forceinline__ unsigned long long walk_stamp()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0): s_memtime returns through the scalar cache
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+// FMODE: the exact rejection filter -- 0 off, 1 gather from GraphTables::qrows, 2 neighbour rows (nbrows)
+template <int NCH, int MINW, int TAGW, int FMODE, bool STAMPS = false>
 __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, const float *__restrict__ xq, int nq, int nprobe,
                                                        int ef, uint32_t *__restrict__ coarse_ids,
                                                        float *__restrict__ coarse_dists,
                                                        uint32_t *__restrict__ visited, size_t vwords,
-                                                       uint32_t *__restrict__ status, uint32_t *__restrict__ next_query)
+                                                       uint32_t *__restrict__ status, uint32_t *__restrict__ next_query,
+                                                       unsigned long long *__restrict__ stamp_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_q = reinterpret_cast<float *>(smem);
-    unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem + (size_t)g.d * sizeof(float));
-    unsigned long long *vt = tail + kTailCap; // [kVisBuckets] when TAGW != 0
+    // gather form of the filter only: the query in byte-row units, (q - q_lo) / q_step
+    float *s_qp = s_q + g.d;
+    const int dp = FMODE == 1 ? g.d : 0;
+    // neighbour-row form: the same in 1/256 steps, four byte planes of 32 words (hi, lo, XL, XH)
+    uint32_t *s_q8 = reinterpret_cast<uint32_t *>(s_qp + dp);
+    unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem + (size_t)(g.d + dp) * sizeof(float) + 512);
+    constexpr int NB = vis_buckets(MINW);
+    unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0}, st_t = 0;
+    unsigned long long *vt = tail + kTailCap; // [NB] when TAGW != 0
     constexpr bool LDSVIS = TAGW != 0;
 
     const int lane = threadIdx.x;
+    constexpr bool prefilter = FMODE != 0;
+    constexpr bool inline_rows = FMODE == 2;
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
     bool bitmap_dirty = true; // the bitmap must be wiped before its first use and after any query that used it
 
@@ -212,6 +274,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         q = __builtin_amdgcn_readfirstlane(q);
         if (q >= nq)
             break;
+        if (STAMPS)
+            st_t = walk_stamp();
 
         // reset the visited set (visited_list_pool.h:25-32 does it by epoch) and stage the query
         if (!LDSVIS || bitmap_dirty) {
@@ -222,12 +286,96 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             bitmap_dirty = false;
         }
         if (LDSVIS)
-            for (int w = lane; w < kVisBuckets; w += 64)
+            for (int w = lane; w < NB; w += 64)
                 vt[w] = 0ull;
         __syncthreads(); // the previous query's readers of s_q are done
-        for (int i = lane; i < g.d; i += 64)
-            s_q[i] = xq[(size_t)q * g.d + i];
+        float qp_sq = 0.f;
+        for (int i = lane; i < g.d; i += 64) {
+            const float v = xq[(size_t)q * g.d + i];
+            s_q[i] = v;
+            if (prefilter) {
+                const float vp = __fdiv_rn(__fsub_rn(v, g.q_lo), g.q_step);
+                if (!inline_rows)
+                    s_qp[i] = vp;
+                qp_sq = fmaf(vp, vp, qp_sq);
+            }
+        }
         __syncthreads(); // also orders the bitmap reset before the atomics below
+        // slack of the rejection test in byte-row units: quantisation error of the worst row, plus what the
+        // rounding of s_qp can move a distance by (<= 2^-22 ||q'||; 2^-18 leaves a factor 16)
+        float pf_slack = 0.f, pf_slack_q = 0.f, pf_bonus = 0.f;
+        int q16_w = 0; // 128 * ||Q / 256||^2 of the two-byte query Q below (floor)
+        int x_const = 0;    // 255 * sum XH
+        bool x_any = false; // some component of this query lies outside the byte range
+        if (prefilter) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                qp_sq += __shfl_xor(qp_sq, off, 64);
+            pf_slack = g.q_errc + 3.9e-6f * sqrtf(qp_sq);
+            if (inline_rows) {
+                // The integer form of the filter.  q' = q_in + q_out: q_in is q' clamped to the byte range and
+                // rounded to 1/256 steps, Q = 256 * hi + lo (two byte planes in LDS); q_out is what the clamp cut
+                // off (zero for most components).  For a byte row c
+                //   ||q' - c||^2 = ||q_in - c||^2 + 2 q_out.(q_in - c) + ||q_out||^2
+                // where  ||q_in - c|| >= ||Q/256 - c|| - ||q_in - Q/256||  (the rounding, measured here: pf_slack_q),
+                //        2 q_out.(q_in - c) >= XL.c + XH.(255 - c)  with XL = floor(2 |q_out|) below the range and
+                //        XH the same above it (two more byte planes; every term of the sum is >= 0),
+                //        ||q_out||^2 is a per-query constant (pf_bonus).
+                // All dot products are exact in integers.
+                float dq_sq = 0.f, bonus = 0.f;
+                int s_hh = 0, s_hl = 0, s_ll = 0, s_xh = 0, s_xl = 0;
+                if (lane < 32) {
+                    uint32_t wh = 0, wl = 0, wxl = 0, wxh = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int comp = 4 * lane + b; // rows are zero beyond d: so is the query
+                        const float vp = comp < g.d ? __fdiv_rn(__fsub_rn(s_q[comp], g.q_lo), g.q_step) : 0.f;
+                        const float fh = fminf(255.f, fmaxf(0.f, floorf(vp))); // NaN -> 0, and the slack turns NaN: no rejections
+                        const float fl = fminf(255.f, fmaxf(0.f, rintf((vp - fh) * 256.f)));
+                        const float qin = fh + fl * 0.00390625f;
+                        const bool below = vp < 0.f, above = vp >= 256.f;
+                        const float e = (below || above) ? 0.f : vp - qin;
+                        dq_sq = fmaf(e, e, dq_sq);
+                        const float out = (below || above) ? fabsf(vp - qin) : 0.f; // |q_out|
+                        bonus = fmaf(out, out, bonus);
+                        const int x = (int)fminf(255.f, floorf(2.f * out));
+                        const int hi = (int)fh, lo = (int)fl;
+                        s_hh += hi * hi;
+                        s_hl += hi * lo;
+                        s_ll += lo * lo;
+                        wh |= (uint32_t)hi << (8 * b);
+                        wl |= (uint32_t)lo << (8 * b);
+                        if (below)
+                            wxl |= (uint32_t)x << (8 * b);
+                        if (above)
+                            wxh |= (uint32_t)x << (8 * b);
+                        s_xl += below ? x : 0;
+                        s_xh += above ? x : 0;
+                    }
+                    s_q8[lane] = wh;
+                    s_q8[32 + lane] = wl;
+                    s_q8[64 + lane] = wxl;
+                    s_q8[96 + lane] = wxh;
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    dq_sq += __shfl_xor(dq_sq, off, 64);
+                    bonus += __shfl_xor(bonus, off, 64);
+                    s_hh += __shfl_xor(s_hh, off, 64);
+                    s_hl += __shfl_xor(s_hl, off, 64);
+                    s_ll += __shfl_xor(s_ll, off, 64);
+                    s_xl += __shfl_xor(s_xl, off, 64);
+                    s_xh += __shfl_xor(s_xh, off, 64);
+                }
+                // 128 * sum Q^2 / 65536 = 128 hh + hl + ll / 512  (< 2^31; the floor only lowers the bound)
+                q16_w = 128 * s_hh + s_hl + (s_ll >> 9);
+                x_any = (s_xl | s_xh) != 0;
+                x_const = 255 * s_xh;
+                pf_slack_q = 1.001f * sqrtf(dq_sq);
+                pf_bonus = 0.999f * bonus;
+                __syncthreads();
+            }
+        }
 
         RSet<NCH> R;
 #pragma unroll
@@ -241,11 +389,16 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             bool ub = false;
             if (lane == 0) {
                 R.r[0] = mk_key(d0, g.enterpoint);
-                (void)visit_test_and_set<TAGW>(g.enterpoint, vt, bm, ub);
+                (void)visit_test_and_set<TAGW, NB>(g.enterpoint, vt, bm, ub);
             }
             __syncthreads();
         }
         bool used_bitmap = false;
+        if (STAMPS) {
+            const unsigned long long t = walk_stamp();
+            st_acc[4] += t - st_t;
+            st_t = t;
+        }
 
         for (;;) {
             // ---- candidateSet.top(): first unexpanded entry of R, ties -> largest id; tail joins at dist == max
@@ -289,32 +442,163 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 __syncthreads();
             }
 
+            if (STAMPS) {
+                const unsigned long long t = walk_stamp();
+                st_acc[0] += t - st_t;
+                st_t = t;
+                st_acc[5] += 1;
+            }
             // ---- expand: links, visited test-and-set, distances (hnswalg.cpp:72-91)
             const uint32_t node = pick_id;
             const int cnt = g.counts[node];
             uint32_t nb = 0;
             if (lane < g.maxM)
                 nb = g.links[(size_t)node * g.maxM + lane]; // issued together with the count
+            // neighbour byte rows of this node (exact rejection filter, below): rows 8i + (lane >> 3), 16-byte
+            // chunk lane & 7 -- four 1 KiB wave reads, in flight together with the link list
+            const bool filter_now = prefilter && n == ef;
+            uint4 nw[4] = {};
+            if (filter_now && inline_rows) {
+                const uint4 *nbr = reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + lane;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    nw[i] = nbr[i * 64];
+            }
             bool fresh = false;
             if (lane < cnt)
-                fresh = visit_test_and_set<TAGW>(nb, vt, bm, used_bitmap);
-            const unsigned long long mask = __ballot(fresh);
-            const int nfresh = __popcll(mask);
+                fresh = visit_test_and_set<TAGW, NB>(nb, vt, bm, used_bitmap);
+            unsigned long long mask = __ballot(fresh);
+            int nfresh = __popcll(mask);
+            if (filter_now && inline_rows) {
+                // (see the gather form below for the bound)  Link lane L is row L of the node's block.
+                const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                const uint4 qhv = *reinterpret_cast<const uint4 *>(s_q8 + 4 * (lane & 7));
+                const uint4 qlv = *reinterpret_cast<const uint4 *>(s_q8 + 32 + 4 * (lane & 7));
+                const uint32_t qh[4] = {qhv.x, qhv.y, qhv.z, qhv.w}, ql[4] = {qlv.x, qlv.y, qlv.z, qlv.w};
+                uint32_t xl[4] = {0u, 0u, 0u, 0u}, xh[4] = {0u, 0u, 0u, 0u};
+                if (x_any) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(s_q8 + 64 + 4 * (lane & 7));
+                    const uint4 b = *reinterpret_cast<const uint4 *>(s_q8 + 96 + 4 * (lane & 7));
+                    xl[0] = a.x, xl[1] = a.y, xl[2] = a.z, xl[3] = a.w;
+                    xh[0] = b.x, xh[1] = b.y, xh[2] = b.z, xh[3] = b.w;
+                }
+                for (int rb = 0;;) {
+                    int S[4], X[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        // 128 * (row.row - 2 (Q/256).row), exact in integers; 128 * Q.Q / 65536 joins below
+                        const uint32_t ws[4] = {nw[i].x, nw[i].y, nw[i].z, nw[i].w};
+                        uint32_t hr = 0, lr = 0, rr = 0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            hr = __builtin_amdgcn_udot4(qh[c], ws[c], hr, false);
+                            lr = __builtin_amdgcn_udot4(ql[c], ws[c], lr, false);
+                            rr = __builtin_amdgcn_udot4(ws[c], ws[c], rr, false);
+                        }
+                        S[i] = oct_sum((int)(128u * rr - 256u * hr - lr)); // row rb + 8i + (lane >> 3)
+                        X[i] = 0;
+                        if (x_any) {
+                            uint32_t xlr = 0, xhr = 0;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                xlr = __builtin_amdgcn_udot4(xl[c], ws[c], xlr, false);
+                                xhr = __builtin_amdgcn_udot4(xh[c], ws[c], xhr, false);
+                            }
+                            X[i] = oct_sum((int)(xlr - xhr));
+                        }
+                    }
+                    const int rel = lane - rb; // this link lane's row within the batch
+                    int mine = 0, minex = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int t = __shfl(S[i], (rel & 7) * 8, 64);
+                        if ((rel >> 3) == i)
+                            mine = t;
+                    }
+                    if (x_any) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const int t = __shfl(X[i], (rel & 7) * 8, 64);
+                            if ((rel >> 3) == i)
+                                minex = t;
+                        }
+                    }
+                    const float m1 = fmaxf(0.f, sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
+                    const float m2 = fmaf(m1, m1, fmaf((float)(minex + x_const), 0.9990234375f, pf_bonus));
+                    const float m = fmaxf(0.f, sqrtf(m2) * 0.9990234375f - pf_slack) * g.q_step;
+                    const float lb = m * m * 0.9990234375f;
+                    if (rel >= 0 && rel < 32 && lb > worst)
+                        fresh = false;
+                    rb += 32;
+                    if (rb >= cnt)
+                        break;
+                    const uint4 *nbr =
+                        reinterpret_cast<const uint4 *>(g.nbrows + ((size_t)node * g.nb_rows + rb) * 128) + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        nw[i] = nbr[i * 64];
+                }
+                mask = __ballot(fresh);
+                nfresh = __popcll(mask);
+            } else if (filter_now && nfresh > 0) {
+                // ---- exact rejection filter.  Once the set is full a row is admitted only if its distance is
+                // below the current maximum (hnswalg.cpp:93), and the maximum never grows.  A lower bound of
+                // the row's float distance that already exceeds it settles the row without reading its d floats:
+                //   ||q - x|| >= q_step * (||q' - bytes|| - errc),
+                // shrunk by 2^-10 twice, which covers every rounding on either side (d <= 2048: the float sums
+                // are within (d+2) * 2^-24 of the real ones).  Rejected rows stay marked visited, as in the
+                // reference; everything else takes the float path below unchanged.
+                const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                const int myrow = __popcll(mask & ((1ull << lane) - 1ull)); // row index of this link lane
+                for (int base = 0; base < nfresh; base += 32) {
+                    const int r = base + (lane >> 1);
+                    const bool active = r < nfresh;
+                    const int src = active ? nth_set_bit(mask, r) : 0;
+                    const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
+                    float S = 0.f;
+                    if (active)
+                        S = byte_row_dist_half(g.qrows + (size_t)nbq * g.d, s_qp, g.d, lane & 1);
+                    S += __shfl_xor(S, 1, 64);
+                    const float m = fmaxf(0.f, sqrtf(S) * 0.9990234375f - pf_slack) * g.q_step;
+                    const float lb = m * m * 0.9990234375f;
+                    const unsigned long long drop = __ballot(active && lb > worst);
+                    const int rel = myrow - base;
+                    if (fresh && rel >= 0 && rel < 32 && ((drop >> (2 * rel)) & 1ull))
+                        fresh = false;
+                }
+                mask = __ballot(fresh);
+                nfresh = __popcll(mask);
+            }
+            if (STAMPS) {
+                const unsigned long long t = walk_stamp();
+                st_acc[1] += t - st_t;
+                st_t = t;
+            }
 
-            // ---- distances, 16 rows per pass (a quad of lanes per row), then admissions in link order
-            for (int base = 0; base < nfresh && ntail >= 0; base += 16) {
-                const int r = base + (lane >> 2);
+            // ---- distances, 8 rows per pass (eight lanes per row), then admissions in link order
+            for (int base = 0; base < nfresh && ntail >= 0; base += 8) {
+                const int r = base + (lane >> 3);
                 const bool active = r < nfresh;
                 const int src = active ? nth_set_bit(mask, r) : 0;
                 const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
                 float dq = 0.f;
                 if (active)
-                    dq = l2_ref_order_quad(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 3);
+                    dq = l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                if (STAMPS) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long t = walk_stamp();
+                    st_acc[2] += t - st_t;
+                    st_t = t;
+                }
                 // Rows that cannot be admitted are dropped wave-wide before the sequential part: once the
                 // set is full its maximum only decreases, so a row failing 'top > dist' (hnswalg.cpp:93)
                 // against the current maximum fails against every later one too.
                 const float top0 = __uint_as_float(key_dist_bits(R.get(n - 1)));
-                unsigned long long cand = __ballot(active && (lane & 3) == 0 && (n < ef || top0 > dq));
+                unsigned long long cand = __ballot(active && (lane & 7) == 0 && (n < ef || top0 > dq));
+                if (STAMPS) {
+                    st_acc[6] += (unsigned long long)__popcll(__ballot(active && (lane & 7) == 0));
+                    st_acc[7] += (unsigned long long)__popcll(cand);
+                }
                 while (cand) { // hnswalg.cpp:93-103, in link order
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1;
@@ -327,6 +611,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     const unsigned long long K = mk_key(dj, idj);
                     const int pos = R.rank_of(K, n, lane);
                     const bool full = n == ef;
+                    if (STAMPS)
+                        st_acc[8] += 1;
                     R.insert_at(K, pos, lane);
                     if (!full)
                         n++;
@@ -350,6 +636,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                         }
                     }
                 }
+                if (STAMPS) {
+                    const unsigned long long t = walk_stamp();
+                    st_acc[3] += t - st_t;
+                    st_t = t;
+                }
             }
             if (ntail < 0)
                 break;
@@ -368,6 +659,32 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
     }
+    if (STAMPS && stamp_out && lane == 0)
+        for (int i = 0; i < 9; i++)
+            atomicAdd(&stamp_out[i], st_acc[i]);
+}
+
+// one 64-thread block per (node, 8 rows): lane -> row (lane >> 3), 16-byte chunk (lane & 7)
+__global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t *__restrict__ nbrows, int nb_rows)
+{
+    const size_t node = blockIdx.x;
+    const int cnt = g.counts[node];
+    const int cpr = g.d >> 4; // 16-byte chunks per source row (<= 8)
+    for (int r0 = 0; r0 < nb_rows; r0 += 8) {
+        const int r = r0 + (threadIdx.x >> 3), c = threadIdx.x & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < cnt && c < cpr)
+            v = reinterpret_cast<const uint4 *>(g.qrows + (size_t)g.links[node * g.maxM + r] * g.d)[c];
+        reinterpret_cast<uint4 *>(nbrows + (node * nb_rows + r) * 128)[c] = v;
+    }
+}
+
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows)
+{
+    if (!g.qrows || g.d > 128 || (g.d & 15) || nb_rows < g.maxM || (nb_rows & 31))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(build_nbrows_kernel, dim3(g.n), dim3(64), 0, s, g, nbrows, nb_rows);
+    return hipGetLastError();
 }
 
 // how many wavefront slots the walk keeps resident for a given ef (sizes the visited bitmaps)
@@ -389,21 +706,43 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
     hipError_t e = hipMemsetAsync(next_query, 0, sizeof(uint32_t), s);
     if (e != hipSuccess)
         return e;
-    // the LDS visited set needs 16-bit tags (n <= 2^26); IVFHNSW_WALK_VIS=bitmap forces the old form (A/B runs)
+    // Waves per SIMD the kernel is built for (register budget and visited-set size follow from it).  Measured
+    // on MI355X (100M / 2^17-centroid workload, ef 80) with the LDS padded to hold 2, 3, 4 waves per SIMD
+    // resident: 2.61, 1.90, 1.54 ms per 10 k queries = 0.48 + 4.26 / waves -- the walk is latency bound per wave.
+    static const int occ = [] {
+        const char *e = getenv("IVFHNSW_WALK_OCC");
+        const int v = e ? atoi(e) : 4;
+        return (v == 5 || v == 6) ? v : 4;
+    }();
+    const int nch = (ef + 63) / 64;
+    const uint32_t nbk = (uint32_t)vis_buckets((nch <= 4 && g.nbrows) ? occ : 4);
+    // the LDS visited set needs 16-bit tags at most; IVFHNSW_WALK_VIS=bitmap forces the global bitmap (A/B runs)
     static const bool force_bitmap = [] {
         const char *e = getenv("IVFHNSW_WALK_VIS");
         return e && e[0] == 'b';
     }();
-    const int tagw = force_bitmap ? 0
-                     : g.n <= 255u * kVisBuckets ? 8
-                     : g.n <= 4095u * kVisBuckets ? 12
-                     : g.n <= 65535u * kVisBuckets ? 16 : 0;
-    const size_t shm = (size_t)g.d * sizeof(float) + (size_t)kTailCap * sizeof(unsigned long long) +
-                       (tagw ? (size_t)kVisBuckets * sizeof(unsigned long long) : 0);
-    const int nch = (ef + 63) / 64;
-#define IVFHNSW_WALK_T(N, W, T)                                                                                     \
-    hipLaunchKernelGGL((hnsw_walk_kernel<N, W, T>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef, coarse_ids, \
-                       coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
+    const int tagw = force_bitmap ? 0 : g.n <= 255u * nbk ? 8 : g.n <= 4095u * nbk ? 12 : g.n <= 65535u * nbk ? 16 : 0;
+    // occupancy experiments only: extra LDS per wavefront lowers the number of resident waves
+    static const size_t lds_pad = [] {
+        const char *e = getenv("IVFHNSW_WALK_LDSPAD");
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
+    const size_t shm = (size_t)(g.d + ((g.qrows && !g.nbrows) ? g.d : 0)) * sizeof(float) + 512 +
+                       (size_t)kTailCap * sizeof(unsigned long long) +
+                       (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
+    const int fmode = g.nbrows ? 2 : g.qrows ? 1 : 0;
+#define IVFHNSW_WALK_F(N, W, T, F)                                                                                    \
+    hipLaunchKernelGGL((hnsw_walk_kernel<N, W, T, F>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,         \
+                       coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
+#define IVFHNSW_WALK_T(N, W, T)          \
+    do {                                 \
+        if (fmode == 2)                  \
+            IVFHNSW_WALK_F(N, W, T, 2);  \
+        else if (fmode == 1)             \
+            IVFHNSW_WALK_F(N, 4, T, 1);  \
+        else                             \
+            IVFHNSW_WALK_F(N, 4, T, 0);  \
+    } while (0)
 #define IVFHNSW_WALK(N, W)             \
     do {                               \
         if (tagw == 8)                 \
@@ -415,25 +754,42 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
         else                           \
             IVFHNSW_WALK_T(N, W, 0);   \
     } while (0)
-    // tuning knob (A/B on the device).  Measured on MI355X (100M / 2^17-centroid workload, ef 80): the
-    // walk is bound by per-wave instruction issue, and 4 waves/SIMD with ~110 VGPRs (2.05 ms per 10 k
-    // queries) beats 8 waves/SIMD with ~55 (2.6 ms), so 4 is the default.
-    static const int occ = [] {
-        const char *e = getenv("IVFHNSW_WALK_OCC");
-        const int v = e ? atoi(e) : 4;
-        return (v == 5 || v == 6 || v == 8) ? v : 4;
-    }();
 #define IVFHNSW_WALK_N(N)              \
     do {                               \
-        if (occ == 8)                  \
-            IVFHNSW_WALK(N, 8);        \
-        else if (occ == 6)             \
+        if (occ == 6)                  \
             IVFHNSW_WALK(N, 6);        \
         else if (occ == 5)             \
             IVFHNSW_WALK(N, 5);        \
         else                           \
             IVFHNSW_WALK(N, 4);        \
     } while (0)
+    static const bool stamps = [] {
+        const char *e = getenv("IVFHNSW_WALK_STAMPS");
+        return e && atoi(e) == 1;
+    }();
+    if (stamps && nch == 2 && tagw == 8 && fmode == 2 && occ == 4) {
+        // diagnostic build: per-segment cycle sums, printed when the process exits (never used for timing claims)
+        static unsigned long long *d_st = nullptr;
+        if (!d_st) {
+            (void)hipMalloc(&d_st, 9 * sizeof(unsigned long long));
+            (void)hipMemset(d_st, 0, 9 * sizeof(unsigned long long));
+            atexit([] {
+                unsigned long long h[9];
+                if (hipMemcpy(h, d_st, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                    const double tot = (double)(h[0] + h[1] + h[2] + h[3] + h[4]);
+                    fprintf(stderr, "[walk stamps] expansions %llu; cycles/expansion: select %.0f, links+visited %.0f, "
+                                    "distances %.0f, admissions %.0f; prologue share %.1f%%; total wave-cycles %.3g\n",
+                            h[5], (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5],
+                            100.0 * h[4] / tot, tot);
+                    fprintf(stderr, "[walk stamps] rows evaluated/expansion %.2f, passing the wave-wide test %.2f, admitted %.2f\n",
+                            (double)h[6] / h[5], (double)h[7] / h[5], (double)h[8] / h[5]);
+                }
+            });
+        }
+        hipLaunchKernelGGL((hnsw_walk_kernel<2, 4, 8, 2, true>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,
+                           coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, d_st);
+        return hipGetLastError();
+    }
     if (nch <= 1) {
         IVFHNSW_WALK_N(1);
     } else if (nch <= 2) {
@@ -448,6 +804,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
 #undef IVFHNSW_WALK_N
 #undef IVFHNSW_WALK
 #undef IVFHNSW_WALK_T
+#undef IVFHNSW_WALK_F
     return hipGetLastError();
 }
 
