@@ -116,6 +116,28 @@ template <int NCH> struct RSet {
             pos += __popcll(__ballot(cc * 64 + lane < n && (r[cc] & ~1ull) < K));
         return pos;
     }
+    // Sorted insertion without a position: every lane decides from its own entry and the one below it
+    // (keep it, become K, or take the one below) -- two DPP shifts and two compares per register, no ballot,
+    // no scalar round trip.  Entries at and beyond n are all-ones or left-overs, never below K's successor:
+    // they shift like real ones and are never read.  K is not in the set (ids are visited once).
+    __device__ __forceinline__ void insert_sorted(unsigned long long K, int lane)
+    {
+#pragma unroll
+        for (int cc = NCH - 1; cc >= 0; cc--) {
+            unsigned long long below = lane_below_u64(r[cc]);
+            bool below_lt = (below & ~1ull) < K;
+            if (cc > 0) {
+                const unsigned long long carry = readlane_u64(r[cc - 1], 63);
+                if (lane == 0) {
+                    below = carry;
+                    below_lt = (carry & ~1ull) < K;
+                }
+            } else if (lane == 0) {
+                below_lt = true; // nothing below entry 0
+            }
+            r[cc] = (r[cc] & ~1ull) < K ? r[cc] : (below_lt ? K : below);
+        }
+    }
     // insert K at sorted position pos, shifting the entries above it up by one (the last one falls off
     // when the set is full: the caller read it first)
     __device__ __forceinline__ void insert_at(unsigned long long K, int pos, int lane)
@@ -593,7 +615,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 // Rows that cannot be admitted are dropped wave-wide before the sequential part: once the
                 // set is full its maximum only decreases, so a row failing 'top > dist' (hnswalg.cpp:93)
                 // against the current maximum fails against every later one too.
-                const float top0 = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                unsigned long long topk = R.get(n - 1); // the set's last entry, carried through the loop
+                const float top0 = __uint_as_float(key_dist_bits(topk));
                 unsigned long long cand = __ballot(active && (lane & 7) == 0 && (n < ef || top0 > dq));
                 if (STAMPS) {
                     st_acc[6] += (unsigned long long)__popcll(__ballot(active && (lane & 7) == 0));
@@ -604,27 +627,26 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     cand &= cand - 1;
                     const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b));
                     const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nbq, b);
-                    const unsigned long long topk = R.get(n - 1);
-                    const float topd = __uint_as_float(key_dist_bits(topk));
-                    if (!(topd > dj || n < ef))
+                    const unsigned long long oldtop = topk;
+                    if (!(__uint_as_float(key_dist_bits(oldtop)) > dj || n < ef))
                         continue;
                     const unsigned long long K = mk_key(dj, idj);
-                    const int pos = R.rank_of(K, n, lane);
                     const bool full = n == ef;
                     if (STAMPS)
                         st_acc[8] += 1;
-                    R.insert_at(K, pos, lane);
+                    R.insert_sorted(K, lane);
                     if (!full)
                         n++;
+                    topk = R.get(n - 1);
                     // bookkeeping of candidates that left topResults but may still be popped
-                    const uint32_t newmax = key_dist_bits(R.get(n - 1));
+                    const uint32_t newmax = key_dist_bits(topk);
                     if (ntail > 0 && key_dist_bits(tail[0]) != newmax)
                         ntail = 0; // lower bound moved below them: dead for good
-                    if (full && !(topk & 1ull) && key_dist_bits(topk) == newmax) {
+                    if (full && !(oldtop & 1ull) && key_dist_bits(oldtop) == newmax) {
                         if (ntail < kTailCap) {
                             __syncthreads();
                             if (lane == 0)
-                                tail[ntail] = topk;
+                                tail[ntail] = oldtop;
                             ntail++;
                             __syncthreads();
                         } else {
