@@ -39,7 +39,14 @@ WORKLOADS = {
     # Grouping + Pruning + OPQ at the reference's preset (examples/run_sift1b_grouping_OPQ.sh:7-53): nsubc 64
     "grouping-100M-pq16-nc131072-nsubc64-opq-pruning": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
     "grouping-10M-pq16-nc16384-nsubc64-opq-pruning": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
+    # The 1B shapes of BASELINE.json configs[2] and [4] on ONE GPU (21 GB of lists; run with --no-cpu-baseline:
+    # the host copy of a 1B corpus is not built).  Parameters: examples/run_sift1b.sh:37-43 (the two paper
+    # points) and examples/run_deep1b_OPQ.sh.
+    "synthetic-1B-pq16-nc993127-nprobe32": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
+    "synthetic-1B-pq16-nc993127-nprobe64": (1_000_000_000, 993127, 128, 16, 64, 30000, 100, 10000),
+    "deep-1B-d96-opq-pq16-nc999973-nprobe128": (1_000_000_000, 999973, 96, 16, 128, 100000, 130, 10000),
 }
+WORKLOAD_FLAGS = {"deep-1B-d96-opq-pq16-nc999973-nprobe128": {"kind": "deep", "opq": True}}
 DEFAULT_WORKLOAD = "synthetic-100M-pq16-nc131072-nprobe32"
 
 
@@ -99,10 +106,13 @@ def main():
     if n_total >= 2 ** 32:
         raise SystemExit("corpus of %d vectors does not fit uint32 ids" % n_total)
     t0 = time.time()
-    tb = synth.make_throughput_tables(args.seed, nc, d, M, n_total)
+    flags = WORKLOAD_FLAGS.get(args.workload, {})
+    kind = flags.get("kind", "sift")
+    tb = synth.make_throughput_tables(args.seed, nc, d, M, n_total, kind=kind)
     rng = np.random.default_rng(args.seed + 1)
-    # queries: SIFT-like points near centroids, so that walks end in populated regions
-    queries = (tb["centroids"][rng.choice(nc, nq)] + rng.normal(0, 12.0, size=(nq, d))).astype(np.float32)
+    # queries: points near centroids, so that walks end in populated regions
+    queries = (tb["centroids"][rng.choice(nc, nq)]
+               + rng.normal(0, 12.0 if kind == "sift" else 0.03, size=(nq, d))).astype(np.float32)
     counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
     centroid_norms = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
     if rank == 0:
@@ -111,6 +121,10 @@ def main():
     grouping = args.workload.startswith("grouping")
     opq_A = None
     vectors = tb["centroids"]
+    if flags.get("opq") and not grouping:
+        # OPQ: the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800);
+        # for a throughput corpus the synthetic centroids simply ARE the rotated ones
+        opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
     if grouping:
         if world != 1:
             raise SystemExit("the grouping workload is single-GPU for now")

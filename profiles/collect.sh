@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash profiles/collect.sh'): the default bench line, the same command under
+# rocprofv3 --kernel-trace --stats, and three PMC passes (each in its own run, counters only with kernel trace).
+# Output under gpurun_out/prof/ (scratch); condense with profiles/summarize.py and commit the summary.
+set -e
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/prof
+rm -rf "$O"; mkdir -p "$O"
+timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
+echo "[collect] bench done"; tail -c 300 "$O/bench.json"
+B="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o run -- $B > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+echo "[collect] stats done"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$O/pmc_fetch" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_fetch.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$O/pmc_write" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_write.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$O/pmc_sq" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_sq.err"
+echo "[collect] pmc done"
+# keep the merge-back small: only the stats and counter tables travel
+find "$O" -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.json" ! -name "*.err" -delete
+find "$O" -name "*.csv" -exec ls -la {} +

@@ -30,7 +30,7 @@ def main():
         for r in csv.DictReader(open(f)):
             if "ivfhnsw_gpu_impl" in r["Kernel_Name"]:
                 agg[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
-        print("\n## rocprofv3 --pmc (%s), average per dispatch\n" % f.split("/")[-3])
+        print("\n## rocprofv3 --pmc (%s), average per dispatch\n" % f.split("/")[-2])
         print("| kernel | counter | dispatches | avg value |")
         print("|---|---|---|---|")
         for (k, c), v in sorted(agg.items()):

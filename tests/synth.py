@@ -192,17 +192,26 @@ def list_sizes(rng, nc, n_total, sigma=0.6, cap=65536):
     return sizes.astype(np.uint64)
 
 
-def make_throughput_tables(seed, nc, d, M, n_total):
-    """Tables of a throughput corpus (no codes): centroids, code books, norm table, list offsets."""
+def make_throughput_tables(seed, nc, d, M, n_total, kind="sift"):
+    """Tables of a throughput corpus (no codes): centroids, code books, norm table, list offsets.
+    kind "sift": byte-ranged non-negative rows; "deep": unit vectors with components of both signs (DEEP1B)."""
     rng = np.random.default_rng(seed)
     dsub = d // M
-    centroids = sift_like(rng, nc, d)
+    if kind == "deep":
+        centroids = rng.normal(0.0, 1.0, size=(nc, d)).astype(np.float32)
+        centroids /= np.linalg.norm(centroids, axis=1, keepdims=True)
+    else:
+        centroids = sift_like(rng, nc, d)
     sizes = list_sizes(rng, nc, n_total)
     offsets = np.zeros(nc + 1, np.uint64)
     offsets[1:] = np.cumsum(sizes)
-    cb = rng.normal(0.0, 12.0, size=(M, 256, dsub)).astype(np.float32)
-    # a reconstructed SIFT-like vector has squared norm around d * (30^2 + 35^2)
-    norm_table = np.sort(rng.normal(d * 2100.0, d * 300.0, size=256)).astype(np.float32)
+    if kind == "deep":
+        cb = rng.normal(0.0, 0.03, size=(M, 256, dsub)).astype(np.float32)
+        norm_table = np.sort(rng.normal(1.0, 0.1, size=256)).astype(np.float32)
+    else:
+        cb = rng.normal(0.0, 12.0, size=(M, 256, dsub)).astype(np.float32)
+        # a reconstructed SIFT-like vector has squared norm around d * (30^2 + 35^2)
+        norm_table = np.sort(rng.normal(d * 2100.0, d * 300.0, size=256)).astype(np.float32)
     return dict(seed=seed, d=d, nc=nc, code_size=M, centroids=centroids, offsets=offsets, pq_centroids=cb,
                 norm_table=norm_table, opq_A=None, nsubc=0)
 
