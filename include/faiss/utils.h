@@ -4,6 +4,7 @@
 
 namespace faiss {
 
+float fvec_L2sqr(const float *x, const float *y, size_t d);
 float fvec_inner_product(const float *x, const float *y, size_t d);
 float fvec_norm_L2sqr(const float *x, size_t d);
 /// nr[i] = ||x_i||^2 for nx vectors of dimension d

@@ -122,6 +122,11 @@ protected:
     bool device_dirty_;
     void ensure_device();
     void device_upload_common();
+    /// construction side: graph (once per quantizer state) and code books (every call) for ivfhnsw_gpu_encode
+    void ensure_encoder();
+    void upload_graph();
+    bool graph_dirty_;
+    const void *graph_uploaded_for_;
 
 private:
     void reconstruct(size_t n, float *x, const float *decoded_residuals, const idx_t *keys);

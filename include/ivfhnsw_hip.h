@@ -151,6 +151,26 @@ int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 
+/* ---- construction side: what IndexIVF_HNSW::add_batch computes before it appends --------
+ *
+ * ivfhnsw_gpu_upload_codebooks: the residual code book (faiss::ProductQuantizer, [M][256][d/M] floats), the norm
+ * code book (ProductQuantizer(1,1,8): 256 floats) and the OPQ matrix (row major [d][d], NULL = no OPQ).
+ * Independent of upload_ivf: an index under construction has no lists yet.  upload_quantizer must have
+ * been called as well (the centroid rows are the graph's vectors).
+ *
+ * ivfhnsw_gpu_encode replaces IndexIVF_HNSW.cpp:75-121 for n base vectors (host pointers):
+ *   idx      = precomputed_idx, or assign(n, x) = searchKnn(x, 1) with efSearch (:68-72) when NULL
+ *   residual = x - centroid[idx]                     (fvec_madd, :258-262)
+ *   codes    = pq->compute_codes([A] residual)       (:92-93)
+ *   norm     = || centroid[idx] + [A^T] pq->decode(codes) ||^2,  norm_codes = norm_pq->compute_codes(norm)
+ * out_idx may be NULL; out_codes [n*code_size]; out_norm_codes [n].  The caller appends them to its lists
+ * (:122-131).  Bytes out: compared bit for bit with the CPU restatement in tests/test_gpu_encode.py. */
+int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, const float *pq_centroids,
+                                 const float *norm_table, const float *opq_A);
+int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t *precomputed_idx, size_t efSearch,
+                       uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes);
+
+
 enum ivfhnsw_stage {
     IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */
     IVFHNSW_STAGE_COARSE = 1, /* quantizer->searchKnn, :248 */

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_upload_grouping", "ivfhnsw_gpu_upload_quantizer", "ivfhnsw_gpu_search", "ivfhnsw_gpu_search_dev",
     "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
-    "ivfhnsw_gpu_memory_bytes",
+    "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
 )
 
 
@@ -84,6 +84,9 @@ def lib():
                                              C.c_void_p]
         L.ivfhnsw_gpu_coarse.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
                                          C.c_void_p]
+        L.ivfhnsw_gpu_upload_codebooks.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_get_stage_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
@@ -229,6 +232,27 @@ class GpuIndex:
         dist = np.empty((q.shape[0], k), np.float32)
         _check(lib().ivfhnsw_gpu_coarse(self._h, q.shape[0], _ptr(q), k, efSearch, _ptr(ids), _ptr(dist)))
         return ids, dist
+
+    # ---- construction side ------------------------------------------------------------------------
+    def upload_codebooks(self, d, code_size, pq_centroids, norm_table, opq_A=None):
+        pq = _np(pq_centroids, np.float32)
+        nt = _np(norm_table, np.float32)
+        assert pq.size == 256 * d and nt.size == 256
+        A = None if opq_A is None else _np(opq_A, np.float32)
+        _check(lib().ivfhnsw_gpu_upload_codebooks(self._h, d, code_size, _ptr(pq), _ptr(nt), _ptr(A)))
+        self._enc_M = code_size
+
+    def encode(self, x, precomputed_idx=None, efSearch=0):
+        """IndexIVF_HNSW::add_batch up to the append loop (IndexIVF_HNSW.cpp:75-121): (idx, codes, norm_codes)."""
+        x = _np(x, np.float32)
+        x = x.reshape(-1, x.shape[-1])
+        n = x.shape[0]
+        pidx = None if precomputed_idx is None else _np(precomputed_idx, np.uint32)
+        idx = np.empty(n, np.uint32)
+        codes = np.empty((n, self._enc_M), np.uint8)
+        ncodes = np.empty(n, np.uint8)
+        _check(lib().ivfhnsw_gpu_encode(self._h, n, _ptr(x), _ptr(pidx), efSearch, _ptr(idx), _ptr(codes), _ptr(ncodes)))
+        return idx, codes, ncodes
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

@@ -88,6 +88,10 @@ struct ivfhnsw_gpu {
     DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows;
     GraphTables gr{};
     bool has_graph = false;
+    // construction side: code books for ivfhnsw_gpu_encode and its workspace
+    DevBuf e_pqc, e_ntab, e_a, e_at, e_x, e_idx, e_dist, e_res, e_tmp, e_codes, e_ncodes;
+    size_t e_d = 0, e_M = 0;
+    bool e_opq = false, has_codebooks = false;
 
     // per-batch workspace
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
@@ -281,7 +285,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 2; }
+int ivfhnsw_gpu_abi_version(void) { return 3; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
@@ -329,7 +333,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
@@ -665,6 +669,106 @@ int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k
     return check_status(h);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// construction side
+int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, const float *pq_centroids,
+                                 const float *norm_table, const float *opq_A)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (d == 0 || code_size == 0 || d % code_size || d / code_size > 64 || !pq_centroids || !norm_table)
+        return fail(IVFHNSW_ERR_INVALID, "bad code books (d %zu, code_size %zu)", d, code_size);
+    h->has_codebooks = false;
+    if ((rc = upload(h->e_pqc, pq_centroids, 256 * d * sizeof(float))))
+        return rc;
+    if ((rc = upload(h->e_ntab, norm_table, 256 * sizeof(float))))
+        return rc;
+    h->e_opq = opq_A != nullptr;
+    if (opq_A) {
+        // both orientations: apply reads A transposed, transform_transpose reads it as it is (launch_opq takes
+        // the matrix of y = B x stored as B^T)
+        std::vector<float> at(d * d);
+        for (size_t i = 0; i < d; i++)
+            for (size_t k = 0; k < d; k++)
+                at[k * d + i] = opq_A[i * d + k];
+        if ((rc = upload(h->e_at, at.data(), d * d * sizeof(float))))
+            return rc;
+        if ((rc = upload(h->e_a, opq_A, d * d * sizeof(float))))
+            return rc;
+    }
+    h->e_d = d;
+    h->e_M = code_size;
+    h->has_codebooks = true;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t *precomputed_idx, size_t efSearch,
+                       uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_codebooks || !h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "encode needs upload_codebooks and upload_quantizer");
+    if ((size_t)h->gr.d != h->e_d)
+        return fail(IVFHNSW_ERR_STATE, "code books are for d = %zu, the quantizer holds d = %d", h->e_d, h->gr.d);
+    if (n == 0)
+        return IVFHNSW_OK;
+    if (!x || !out_codes || !out_norm_codes)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer");
+    if (!precomputed_idx && efSearch == 0)
+        return fail(IVFHNSW_ERR_INVALID, "efSearch 0 (assign runs searchKnn(x, 1))");
+    const size_t d = h->e_d, M = h->e_M;
+    const size_t kChunk = (size_t)1 << 18; // 128 MB of vectors at d = 128 per buffer
+    for (size_t i0 = 0; i0 < n; i0 += kChunk) {
+        const size_t m = std::min(kChunk, n - i0);
+        if ((rc = h->e_x.ensure(m * d * sizeof(float))) || (rc = h->e_res.ensure(m * d * sizeof(float))) ||
+            (rc = h->e_tmp.ensure(m * d * sizeof(float))) || (rc = h->e_idx.ensure(m * sizeof(uint32_t))) ||
+            (rc = h->e_dist.ensure(m * sizeof(float))) || (rc = h->e_codes.ensure(m * M)) ||
+            (rc = h->e_ncodes.ensure(m)))
+            return rc;
+        float *dx = h->e_x.as<float>(), *res = h->e_res.as<float>(), *tmp = h->e_tmp.as<float>();
+        uint32_t *idx = h->e_idx.as<uint32_t>();
+        HIP_TRY(hipMemcpyAsync(dx, x + i0 * d, m * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if (precomputed_idx) {
+            for (size_t i = 0; i < m; i++)
+                if (precomputed_idx[i0 + i] >= h->gr.n)
+                    return fail(IVFHNSW_ERR_INVALID, "precomputed_idx[%zu] = %u out of range", i0 + i,
+                                precomputed_idx[i0 + i]);
+            HIP_TRY(hipMemcpyAsync(idx, precomputed_idx + i0, m * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        } else if ((rc = ivfhnsw_gpu_coarse_dev(h, m, dx, 1, efSearch, idx, h->e_dist.as<float>()))) {
+            return rc;
+        }
+        // residual = x - centroid[idx]; with OPQ the code is taken of A * residual
+        HIP_TRY(launch_madd_rows(h->stream, dx, -1.f, h->gr.vectors, idx, res, m, (int)d));
+        const float *enc_in = res;
+        if (h->e_opq) {
+            HIP_TRY(launch_opq(h->stream, h->e_at.as<float>(), res, tmp, (int)m, (int)d));
+            enc_in = tmp;
+        }
+        HIP_TRY(launch_pq_encode(h->stream, enc_in, h->e_pqc.as<float>(), h->e_codes.as<uint8_t>(), m, (int)d, (int)M));
+        // decode -> rotate back -> + centroid -> squared norm -> norm code
+        float *dec = h->e_opq ? res : tmp; // the buffer the encoder did not read
+        HIP_TRY(launch_pq_decode(h->stream, h->e_codes.as<uint8_t>(), h->e_pqc.as<float>(), dec, m, (int)d, (int)M));
+        float *back = dec;
+        if (h->e_opq) {
+            HIP_TRY(launch_opq(h->stream, h->e_a.as<float>(), dec, tmp, (int)m, (int)d));
+            back = tmp;
+        }
+        HIP_TRY(launch_madd_rows(h->stream, back, 1.f, h->gr.vectors, idx, dx, m, (int)d)); // x is spent: reuse
+        HIP_TRY(launch_norm_codes(h->stream, dx, h->e_ntab.as<float>(), h->e_ncodes.as<uint8_t>(), nullptr, m, (int)d));
+        HIP_TRY(hipMemcpyAsync(out_codes + i0 * M, h->e_codes.p, m * M, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out_norm_codes + i0, h->e_ncodes.p, m, hipMemcpyDeviceToHost, h->stream));
+        if (out_idx)
+            HIP_TRY(hipMemcpyAsync(out_idx + i0, idx, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if ((rc = check_status(h)))
+            return rc;
+    }
+    return IVFHNSW_OK;
+}
+
 static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
                             const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                             int64_t *d_labels, int64_t *d_out_keys);
@@ -942,7 +1046,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

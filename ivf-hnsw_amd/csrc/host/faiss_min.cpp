@@ -142,26 +142,34 @@ void ProductQuantizer::decode(const uint8_t *code, float *x, size_t n) const
         decode(code + i * code_size, x + i * d);
 }
 
-static float l2_plain(const float *a, const float *b, size_t n)
+// SSE order of faiss's fvec_L2sqr: 4 partial sums over blocks of 4, zero-padded tail, (s0+s1)+(s2+s3)
+float fvec_L2sqr(const float *x, const float *y, size_t d)
 {
-    float s = 0.f;
-    for (size_t i = 0; i < n; i++) {
-        const float t = a[i] - b[i];
-        s += t * t;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    size_t i = 0;
+    for (; i + 4 <= d; i += 4)
+        for (int l = 0; l < 4; l++) {
+            const float t = x[i + l] - y[i + l];
+            s[l] = s[l] + t * t;
+        }
+    for (int l = 0; i + l < d; l++) {
+        const float t = x[i + l] - y[i + l];
+        s[l] = s[l] + t * t;
     }
-    return s;
+    return (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+// faiss: first code word with dis < mindis, the search starting at mindis = 1e20 and index -1
 void ProductQuantizer::compute_code(const float *x, uint8_t *code) const
 {
     for (size_t m = 0; m < M; m++) {
-        float best = INFINITY;
-        size_t arg = 0;
+        float best = 1e20f;
+        int arg = -1;
         for (size_t c = 0; c < ksub; c++) {
-            const float dist = l2_plain(x + m * dsub, get_centroids(m, c), dsub);
+            const float dist = fvec_L2sqr(x + m * dsub, get_centroids(m, c), dsub);
             if (dist < best) {
                 best = dist;
-                arg = c;
+                arg = (int)c;
             }
         }
         code[m] = (uint8_t)arg;
@@ -193,7 +201,7 @@ void ProductQuantizer::train(int n, const float *x)
                 float best = INFINITY;
                 uint32_t arg = 0;
                 for (size_t c = 0; c < ksub; c++) {
-                    const float dist = l2_plain(x + (size_t)i * d + m * dsub, get_centroids(m, c), dsub);
+                    const float dist = fvec_L2sqr(x + (size_t)i * d + m * dsub, get_centroids(m, c), dsub);
                     if (dist < best) {
                         best = dist;
                         arg = (uint32_t)c;

@@ -25,7 +25,7 @@ namespace {
 IndexIVF_HNSW::IndexIVF_HNSW(size_t dim, size_t ncentroids, size_t bytes_per_code, size_t nbits_per_idx,
                              size_t max_group_size)
     : d(dim), nc(ncentroids), code_size(0), quantizer(nullptr), pq(nullptr), norm_pq(nullptr), opq_matrix(nullptr),
-      do_opq(false), nprobe(1), max_codes(0), M(16), gpu_(nullptr), device_dirty_(true), up_pq_(nullptr),
+      do_opq(false), nprobe(1), max_codes(0), M(16), gpu_(nullptr), device_dirty_(true), graph_dirty_(true), graph_uploaded_for_(nullptr), up_pq_(nullptr),
       up_norm_pq_(nullptr), up_opq_(nullptr), up_quantizer_(nullptr), up_total_(0), up_do_opq_(false)
 {
     std::memset(&hdr_idx, 0, sizeof(hdr_idx));
@@ -56,6 +56,7 @@ void IndexIVF_HNSW::build_quantizer(const char *path_data, const char *path_info
     hdr_idx.efConstruction = (uint32_t)efConstruction;
     M = M_;
     device_dirty_ = true;
+    graph_dirty_ = true;
     if (exists(path_info) && exists(path_edges)) {
         quantizer = new hnswlib::HierarchicalNSW(path_info, path_data, path_edges);
         quantizer->efSearch = efConstruction;
@@ -129,6 +130,18 @@ void IndexIVF_HNSW::device_upload_common()
     if (ivfhnsw_gpu_upload_ivf(gpu_, &desc))
         gpu_fail("ivfhnsw_gpu_upload_ivf");
 
+    upload_graph();
+
+    up_pq_ = pq;
+    up_norm_pq_ = norm_pq;
+    up_opq_ = opq_matrix;
+    up_quantizer_ = quantizer;
+    up_total_ = total;
+    up_do_opq_ = do_opq;
+}
+
+void IndexIVF_HNSW::upload_graph()
+{
     // node records [count][maxM links][d floats] -> three arrays
     const size_t maxM = quantizer->maxM_, n = quantizer->maxelements_;
     std::vector<uint8_t> cnt(n);
@@ -142,13 +155,28 @@ void IndexIVF_HNSW::device_upload_common()
     }
     if (ivfhnsw_gpu_upload_quantizer(gpu_, n, d, maxM, quantizer->enterpoint_node, cnt.data(), lnk.data(), vec.data()))
         gpu_fail("ivfhnsw_gpu_upload_quantizer");
+    graph_dirty_ = false;
+    graph_uploaded_for_ = quantizer;
+}
 
-    up_pq_ = pq;
-    up_norm_pq_ = norm_pq;
-    up_opq_ = opq_matrix;
-    up_quantizer_ = quantizer;
-    up_total_ = total;
-    up_do_opq_ = do_opq;
+void IndexIVF_HNSW::ensure_encoder()
+{
+    if (!quantizer)
+        throw std::runtime_error("IndexIVF_HNSW: no quantizer (call build_quantizer first)");
+    if (!pq || !norm_pq)
+        throw std::runtime_error("IndexIVF_HNSW::add_batch: pq / norm_pq are not set (train_pq or read them first)");
+    if (do_opq && !opq_matrix)
+        throw std::runtime_error("IndexIVF_HNSW: do_opq is set but opq_matrix is null");
+    if (pq->centroids.size() != 256 * d || norm_pq->centroids.size() != 256)
+        throw std::runtime_error("IndexIVF_HNSW: pq / norm_pq have unexpected shapes");
+    if (!gpu_ && ivfhnsw_gpu_create(0, &gpu_))
+        gpu_fail("ivfhnsw_gpu_create");
+    if (graph_dirty_ || graph_uploaded_for_ != quantizer)
+        upload_graph();
+    // 192 KB: sent with every batch, so a driver that retrains or swaps pq / opq_matrix in place is always seen
+    if (ivfhnsw_gpu_upload_codebooks(gpu_, d, code_size, pq->centroids.data(), norm_pq->centroids.data(),
+                                     do_opq ? opq_matrix->A.data() : nullptr))
+        gpu_fail("ivfhnsw_gpu_upload_codebooks");
 }
 
 void IndexIVF_HNSW::sync_to_device()
@@ -269,33 +297,13 @@ void IndexIVF_HNSW::reconstruct(size_t n, float *x, const float *decoded_residua
 
 void IndexIVF_HNSW::add_batch(size_t n, const float *x, const idx_t *xids, const idx_t *precomputed_idx)
 {
-    std::vector<idx_t> own;
-    const idx_t *idx = precomputed_idx;
-    if (!idx) {
-        own.resize(n);
-        assign(n, x, own.data());
-        idx = own.data();
-    }
-    // residual -> (rotate) -> encode -> decode -> (rotate back) -> reconstruct -> norm -> norm code
-    std::vector<float> res(n * d), tmp;
-    compute_residuals(n, x, res.data(), idx);
-    if (do_opq) {
-        tmp = res;
-        opq_matrix->apply_noalloc((long)n, tmp.data(), res.data());
-    }
-    std::vector<uint8_t> xcodes(n * code_size);
-    pq->compute_codes(res.data(), xcodes.data(), n);
-    std::vector<float> dec(n * d);
-    pq->decode(xcodes.data(), dec.data(), n);
-    if (do_opq) {
-        tmp = dec;
-        opq_matrix->transform_transpose((long)n, tmp.data(), dec.data());
-    }
-    std::vector<float> rec(n * d), nrm(n);
-    reconstruct(n, rec.data(), dec.data(), idx);
-    faiss::fvec_norms_L2sqr(nrm.data(), rec.data(), d, n);
-    std::vector<uint8_t> ncodes(n);
-    norm_pq->compute_codes(nrm.data(), ncodes.data(), n);
+    // assign -> residual -> (rotate) -> encode -> decode -> (rotate back) -> reconstruct -> norm -> norm code
+    // (the reference's IndexIVF_HNSW.cpp:75-121) is one call on the device; the append loop (:122-131) stays here
+    ensure_encoder();
+    std::vector<idx_t> idx(n);
+    std::vector<uint8_t> xcodes(n * code_size), ncodes(n);
+    if (ivfhnsw_gpu_encode(gpu_, n, x, precomputed_idx, quantizer->efSearch, idx.data(), xcodes.data(), ncodes.data()))
+        gpu_fail("ivfhnsw_gpu_encode");
     for (size_t i = 0; i < n; i++) {
         const idx_t key = idx[i];
         ids[key].push_back(xids[i]);
@@ -425,6 +433,7 @@ void IndexIVF_HNSW::rotate_quantizer()
         opq_matrix->apply_noalloc(1, tmp.data(), c);
     }
     device_dirty_ = true;
+    graph_dirty_ = true;
 }
 
 } // namespace ivfhnsw

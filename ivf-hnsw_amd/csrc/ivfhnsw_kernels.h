@@ -114,6 +114,13 @@ int coarse4_waves_resident();
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
 constexpr uint32_t kStatusTopkStreamOverflow = 2u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
+// construction side (kernels_encode.hip): IndexIVF_HNSW.cpp:75-121
+hipError_t launch_madd_rows(hipStream_t s, const float *a, float bf, const float *table, const uint32_t *idx, float *c,
+                            size_t n, int d);
+hipError_t launch_pq_encode(hipStream_t s, const float *r, const float *cb, uint8_t *codes, size_t n, int d, int M);
+hipError_t launch_pq_decode(hipStream_t s, const uint8_t *codes, const float *cb, float *dec, size_t n, int d, int M);
+hipError_t launch_norm_codes(hipStream_t s, const float *rec, const float *ntab, uint8_t *norm_codes, float *norms_out,
+                             size_t n, int d);
 // nbrows[i][j] = qrows[links[i][j]] for j < counts[i], zero otherwise (GraphTables::nbrows)
 hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows);
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);

@@ -906,6 +906,108 @@ void orc_rotate_quantizer(orc_hnsw *g, const float *A)
 }
 
 /* =============================================================================================
+ * Construction side: IndexIVF_HNSW::add_batch, IndexIVF_HNSW.cpp:75-121.
+ * faiss leafs (spec of its SSE build, absent from the reference tree -- parity unpinned):
+ *   fvec_madd(n, a, bf, b, c): c = a + bf * b, mul then add;
+ *   fvec_L2sqr: 4 partial sums over blocks of 4, zero-padded tail, (s0+s1)+(s2+s3);
+ *   ProductQuantizer::compute_code: per sub-quantizer the first c with dis < mindis, mindis starting
+ *   at 1e20 and the index at -1 (stored as uint8);  decode: concatenated code words;
+ *   LinearTransform::apply / transform_transpose: sgemm in faiss, order unspecified -- the k-ordered
+ *   fmaf chain is the contract here (orc_opq_apply);  fvec_norm_L2sqr = inner product order.
+ * ============================================================================================= */
+static float l2_sse_order(const float *x, const float *y, size_t d)
+{
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    size_t i = 0;
+    for (; i + 4 <= d; i += 4)
+        for (int l = 0; l < 4; l++) {
+            float t = x[i + l] - y[i + l];
+            s[l] = s[l] + t * t;
+        }
+    for (int l = 0; i + l < d; l++) {
+        float t = x[i + l] - y[i + l];
+        s[l] = s[l] + t * t;
+    }
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+static void pq_compute_code(const float *cb, size_t M, size_t dsub, const float *x, uint8_t *code)
+{
+    for (size_t m = 0; m < M; m++) {
+        float mindis = 1e20f;
+        int idxm = -1;
+        for (size_t c = 0; c < 256; c++) {
+            float dis = l2_sse_order(x + m * dsub, cb + (m * 256 + c) * dsub, dsub);
+            if (dis < mindis) {
+                mindis = dis;
+                idxm = (int)c;
+            }
+        }
+        code[m] = (uint8_t)idxm;
+    }
+}
+
+void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const uint32_t *precomputed_idx,
+                          uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes, float *out_norms)
+{
+    const size_t d = ix->d, M = ix->code_size, dsub = d / M;
+    const orc_hnsw *g = ix->quantizer;
+#pragma omp parallel
+    {
+        float *res = (float *)malloc(3 * d * sizeof(float)), *tmp = res + d, *rec = res + 2 * d;
+        /* every concurrent caller of searchKnn gets its own visited list (visited_list_pool.h:55-76) */
+        uint16_t *mass = precomputed_idx ? NULL : (uint16_t *)calloc(g->maxelements, sizeof(uint16_t));
+        uint16_t epoch = (uint16_t)-1;
+        unsigned long long dc = 0;
+#pragma omp for schedule(static)
+        for (long ii = 0; ii < (long)n; ii++) {
+            const size_t i = (size_t)ii;
+            const float *xi = x + i * d;
+            uint32_t key = 0;
+            if (precomputed_idx) {
+                key = precomputed_idx[i]; /* :79-80 */
+            } else {
+                float dist;
+                hnsw_search_knn_tl(g, xi, ix->efSearch, 1, &key, &dist, mass, &epoch, &dc); /* :68-72 */
+            }
+            if (out_idx)
+                out_idx[i] = key;
+            const float *cen = g->vectors + (size_t)key * d;
+            for (size_t j = 0; j < d; j++) /* :86-87 compute_residuals -> fvec_madd(d, x, -1, centroid, r) */
+                res[j] = xi[j] + -1.0f * cen[j];
+            const float *enc = res;
+            if (ix->do_opq) { /* :90-94 */
+                orc_opq_apply(ix->opq_A, res, d, tmp);
+                enc = tmp;
+            }
+            uint8_t *code = out_codes + i * M;
+            pq_compute_code(ix->pq_centroids, M, dsub, enc, code); /* :97-98 */
+            float *dec = ix->do_opq ? res : tmp;
+            for (size_t m = 0; m < M; m++) /* :101-102 pq->decode */
+                memcpy(dec + m * dsub, ix->pq_centroids + (m * 256 + code[m]) * dsub, dsub * sizeof(float));
+            const float *back = dec;
+            if (ix->do_opq) { /* :105-109 transform_transpose: x[k] = sum_i A[i][k] * y[i] */
+                for (size_t k = 0; k < d; k++) {
+                    float acc = 0.0f;
+                    for (size_t r = 0; r < d; r++)
+                        acc = fmaf(ix->opq_A[r * d + k], dec[r], acc);
+                    tmp[k] = acc;
+                }
+                back = tmp;
+            }
+            for (size_t j = 0; j < d; j++) /* :112-113 reconstruct -> fvec_madd(d, decoded, 1, centroid, x) */
+                rec[j] = back[j] + 1.0f * cen[j];
+            float norm = orc_inner_product_sse_order(rec, rec, d); /* :116-117 */
+            if (out_norms)
+                out_norms[i] = norm;
+            pq_compute_code(ix->norm_table, 1, 1, &norm, out_norm_codes + i); /* :120-121 */
+        }
+        free(res);
+        free(mass);
+    }
+}
+
+/* =============================================================================================
  * .index files -- utils.h:53-81 (uint32 count + raw elements), IndexIVF_HNSW.cpp:637-663,758-779,
  * IndexIVF_HNSW_Grouping.cpp:397-483
  * ============================================================================================= */

@@ -126,6 +126,14 @@ void orc_search_batch(const orc_index *ix, size_t nq, size_t k, const float *x, 
                       long *labels, uint32_t *out_coarse_ids, float *out_coarse_dists, orc_stats *st_sum,
                       int nthreads);
 
+/* Construction side, IndexIVF_HNSW.cpp:75-121 (add_batch up to the append loop): for n base vectors
+ * idx = precomputed_idx or assign() (:68-72, searchKnn(x, 1) with ix->efSearch), residual (:258-262 fvec_madd
+ * with -1), [OPQ apply], pq->compute_codes, pq->decode, [OPQ transform_transpose], reconstruct (fvec_madd
+ * with +1), fvec_norms_L2sqr, norm_pq->compute_codes.  Uses ix->quantizer, pq_centroids, norm_table, opq_A /
+ * do_opq, d, code_size.  out_idx may be NULL; out_norms (the float norms before coding) may be NULL. */
+void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const uint32_t *precomputed_idx,
+                          uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes, float *out_norms);
+
 /* IndexIVF_HNSW.cpp:781-787 / Grouping.cpp:620-631. */
 void orc_compute_centroid_norms(const orc_hnsw *g, float *centroid_norms);
 void orc_compute_inter_centroid_dists(const orc_hnsw *g, size_t nsubc, const uint32_t *nn_idx, float *out);

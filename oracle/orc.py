@@ -78,6 +78,7 @@ def lib():
         L.orc_search_grouping.argtypes = [ip, sz, vp, vp, vp, sp]
         L.orc_search_grouping_coarse.argtypes = [ip, sz, vp, vp, vp, vp, vp, sp]
         L.orc_search_batch.argtypes = [ip, sz, sz, vp, vp, vp, vp, vp, sp, C.c_int]
+        L.orc_add_batch_encode.argtypes = [ip, sz, vp, vp, vp, vp, vp, vp]
         L.orc_compute_centroid_norms.argtypes = [vp, vp]
         L.orc_compute_inter_centroid_dists.argtypes = [vp, sz, vp, vp]
         L.orc_rotate_quantizer.argtypes = [vp, vp]
@@ -255,6 +256,19 @@ class Index:
     def set_params(self, nprobe, max_codes, efSearch, do_pruning=False):
         self.ix.nprobe, self.ix.max_codes, self.ix.efSearch = nprobe, max_codes, efSearch
         self.ix.do_pruning = 1 if do_pruning else 0
+
+    def add_batch_encode(self, x, precomputed_idx=None):
+        """IndexIVF_HNSW.cpp:75-121 for the rows of x: (idx, codes, norm_codes, norms).  Uses efSearch of
+        set_params for the assignment when precomputed_idx is None."""
+        x = np.ascontiguousarray(x, np.float32)
+        n = x.shape[0]
+        pidx = None if precomputed_idx is None else np.ascontiguousarray(precomputed_idx, np.uint32)
+        idx = np.empty(n, np.uint32)
+        codes = np.empty((n, self.ix.code_size), np.uint8)
+        ncodes = np.empty(n, np.uint8)
+        norms = np.empty(n, np.float32)
+        lib().orc_add_batch_encode(C.byref(self.ix), n, _p(x), _p(pidx), _p(idx), _p(codes), _p(ncodes), _p(norms))
+        return idx, codes, ncodes, norms
 
     def search(self, x, k=1):
         """One query through the reference's single-query entry point."""

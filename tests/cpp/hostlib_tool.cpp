@@ -94,6 +94,46 @@ static int run(int argc, char **argv)
         delete vt;
         return 0;
     }
+    if (cmd == "add_batch" && argc == 16) {
+        // the construction sequence of the reference's drivers (tests/test_ivfhnsw_sift1b.cpp:47-67,100-160):
+        // build/load the quantizer, load pq / norm_pq / opq, add the base vectors batch by batch, write the index
+        const size_t d = atol(argv[2]), nc = atol(argv[3]), cs = atol(argv[4]);
+        const char *centroids = argv[5], *info = argv[6], *edges = argv[7], *ppq = argv[8], *pnorm = argv[9],
+                   *popq = argv[10], *pbase = argv[11], *pidx = argv[12], *pindex = argv[15];
+        const size_t n = atol(argv[13]), batch = atol(argv[14]);
+        IndexIVF_HNSW *index = new IndexIVF_HNSW(d, nc, cs, 8);
+        index->build_quantizer(centroids, info, edges, 16, 500);
+        index->do_opq = strcmp(popq, "-") != 0;
+        delete index->pq;
+        index->pq = faiss::read_ProductQuantizer(ppq);
+        if (index->do_opq)
+            index->opq_matrix = dynamic_cast<faiss::LinearTransform *>(faiss::read_VectorTransform(popq));
+        delete index->norm_pq;
+        index->norm_pq = faiss::read_ProductQuantizer(pnorm);
+        index->quantizer->efSearch = 40;
+        std::vector<float> x(n * d);
+        {
+            std::ifstream in(pbase, std::ios::binary);
+            readXvec<float>(in, x.data(), d, n);
+        }
+        std::vector<uint32_t> pre;
+        if (strcmp(pidx, "-") != 0) { // precomputed assignments, one uint32 per vector
+            pre.resize(n);
+            std::ifstream in(pidx, std::ios::binary);
+            in.read((char *)pre.data(), n * sizeof(uint32_t));
+        }
+        std::vector<uint32_t> xids(n);
+        for (size_t i = 0; i < n; i++)
+            xids[i] = (uint32_t)(1000 + i);
+        for (size_t i0 = 0; i0 < n; i0 += batch) {
+            const size_t m = std::min(batch, n - i0);
+            index->add_batch(m, x.data() + i0 * d, xids.data() + i0, pre.empty() ? nullptr : pre.data() + i0);
+        }
+        index->compute_centroid_norms();
+        index->write(pindex);
+        delete index;
+        return 0;
+    }
     if (cmd == "search" && argc == 22) {
         const bool grp = !strcmp(argv[2], "grouping");
         const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);

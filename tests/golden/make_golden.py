@@ -40,7 +40,26 @@ def run_case(kw, nprobe, max_codes, ef, pruning):
                 counts=np.array([st.ncode, st.nseg, st.dist_evals], np.uint64), input_digest=digest), c
 
 
+ENCODE_CASES = {
+    # name: make_encode_case arguments (construction side, IndexIVF_HNSW.cpp:75-121)
+    "encode_pq16_opq": dict(seed=111, nc=300, d=128, M=16, opq=True, n=700),
+    "encode_pq8_d96": dict(seed=112, nc=300, d=96, M=8, opq=False, n=700, kind="deep"),
+}
+
+
+def run_encode_case(kw):
+    s = synth.make_encode_case(**kw)
+    idx, codes, ncodes, norms = s["ox"].add_batch_encode(s["x"])
+    digest = np.array([int(s["x"].view(np.uint32).astype(np.uint64).sum()), int(s["graph"].links.astype(np.uint64).sum()),
+                       int(s["cb"].view(np.uint32).astype(np.uint64).sum())], np.uint64)
+    return dict(idx=idx, codes=codes, norm_codes=ncodes, norms=norms, input_digest=digest), s
+
+
 if __name__ == "__main__":
+    for name, kw in ENCODE_CASES.items():
+        out, _ = run_encode_case(kw)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, out["codes"][:2], out["norm_codes"][:8])
     for name, (kw, nprobe, max_codes, ef, pruning) in CASES.items():
         out, _ = run_case(kw, nprobe, max_codes, ef, pruning)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

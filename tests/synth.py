@@ -333,3 +333,27 @@ def make_grouping_tables(seed, tb, nsubc, device=None):
     icd = g.inter_centroid_dists(nn)
     g.free()
     return dict(nsubc=nsubc, nn_centroid_idxs=nn, alphas=alphas, subgroup_sizes=sg, inter_centroid_dists=icd)
+
+
+def make_encode_case(seed, nc, d, M, opq, n, hnsw_M=8, kind="sift"):
+    """Inputs of an add_batch parity case (construction side): centroids, their reference-identical graph, code
+    books, optional OPQ matrix, base vectors, and the oracle index that encodes them."""
+    from oracle import orc
+    rng = np.random.default_rng(seed)
+    if kind == "sift":
+        cents = sift_like(rng, nc, d)
+        x = (cents[rng.choice(nc, n)] + rng.normal(0, 15.0, size=(n, d))).astype(np.float32)
+        cb = rng.normal(0.0, 9.0, size=(M, 256, d // M)).astype(np.float32)
+        nt = np.sort(rng.normal(d * 2100.0, d * 300.0, size=256)).astype(np.float32)
+    else:
+        cents = rng.normal(0, 1, size=(nc, d))
+        cents = (cents / np.linalg.norm(cents, axis=1, keepdims=True)).astype(np.float32)
+        x = (cents[rng.choice(nc, n)] + rng.normal(0, 0.05, size=(n, d))).astype(np.float32)
+        cb = rng.normal(0.0, 0.03, size=(M, 256, d // M)).astype(np.float32)
+        nt = np.sort(rng.normal(1.0, 0.1, size=256)).astype(np.float32)
+    graph = orc.Hnsw.build(cents, M=hnsw_M, efConstruction=60)
+    A = random_rotation(rng, d) if opq else None
+    ox = orc.Index(d, M, graph, cb, nt, np.zeros(nc + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, M), np.uint8),
+                   np.zeros(0, np.uint8), np.zeros(nc, np.float32), opq_A=A)
+    ox.set_params(1, 0, 40)
+    return dict(cents=cents, x=x, cb=cb, nt=nt, A=A, graph=graph, ox=ox, d=d, M=M, nc=nc)

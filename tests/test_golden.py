@@ -63,3 +63,33 @@ def test_device_reproduces_golden(gpu, name):
         o1, o2 = np.lexsort((lab5[i], dist5[i])), np.lexsort((gold["lab5"][i], gold["dist5"][i]))
         assert np.array_equal(lab5[i][o1], gold["lab5"][i][o2])
         assert np.array_equal(dist5[i][o1].view(np.uint32), gold["dist5"][i][o2].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------- construction side
+ENC_NAMES = sorted(make_golden.ENCODE_CASES)
+
+
+@pytest.mark.parametrize("name", ENC_NAMES)
+def test_oracle_reproduces_encode_golden(name):
+    out, _ = make_golden.run_encode_case(make_golden.ENCODE_CASES[name])
+    g = _load(name)
+    assert np.array_equal(out["input_digest"], g["input_digest"]), "the case generator changed"
+    for key in ("idx", "codes", "norm_codes"):
+        assert np.array_equal(out[key], g[key]), key
+    assert np.array_equal(out["norms"].view(np.uint32), g["norms"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ENC_NAMES)
+def test_device_reproduces_encode_golden(gpu, name):
+    import synth
+    s = synth.make_encode_case(**make_golden.ENCODE_CASES[name])
+    g = gpu()
+    gr = s["graph"]
+    g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+    g.upload_codebooks(s["d"], s["M"], s["cb"], s["nt"], s["A"])
+    gold = _load(name)
+    idx, codes, ncodes = g.encode(s["x"], efSearch=40)
+    assert np.array_equal(idx, gold["idx"])
+    assert np.array_equal(codes, gold["codes"])
+    assert np.array_equal(ncodes, gold["norm_codes"])

@@ -364,3 +364,91 @@ def test_hnsw_files_layout(tmp_path):
     for i in range(50):
         assert np.array_equal(g2.links[i, :g.counts[i]], g.links[i, :g.counts[i]])
     assert os.path.getsize(pe) == 4 * 50 + 4 * int(g.counts.sum())
+
+
+# ---------------------------------------------------------------------------------------------- construction side
+def np_l2_sse(x, y):
+    s = np.zeros(4, F)
+    n, i = len(x), 0
+    while i + 4 <= n:
+        t = (x[i:i + 4] - y[i:i + 4]).astype(F)
+        s = (s + (t * t).astype(F)).astype(F)
+        i += 4
+    for l in range(n - i):
+        t = F(x[i + l] - y[i + l])
+        s[l] = F(s[l] + F(t * t))
+    return F(F(s[0] + s[1]) + F(s[2] + s[3]))
+
+
+def np_add_batch_encode(x, idx, cents, cb, nt, A):
+    """Independent float32 evaluation of IndexIVF_HNSW.cpp:86-121 in the order the oracle documents."""
+    M, _, dsub = cb.shape
+    d = cents.shape[1]
+    codes = np.zeros((len(x), M), np.uint8)
+    ncodes = np.zeros(len(x), np.uint8)
+    norms = np.zeros(len(x), F)
+    for i, xi in enumerate(x):
+        cen = cents[idx[i]]
+        res = (xi + (F(-1.0) * cen).astype(F)).astype(F)
+        enc = res
+        if A is not None:
+            enc = np.array([_fma_chain(A[r], res) for r in range(d)], F)
+        for m in range(M):
+            best, arg = F(1e20), -1
+            for c in range(256):
+                dis = np_l2_sse(enc[m * dsub:(m + 1) * dsub], cb[m, c])
+                if dis < best:
+                    best, arg = dis, c
+            codes[i, m] = arg & 0xff
+        dec = np.concatenate([cb[m, codes[i, m]] for m in range(M)]).astype(F)
+        if A is not None:
+            dec = np.array([_fma_chain(A[:, k], dec) for k in range(d)], F)
+        rec = (dec + (F(1.0) * cen).astype(F)).astype(F)
+        norms[i] = np_ip_sse(rec, rec)
+        best, arg = F(1e20), -1
+        for c in range(256):
+            t = F(norms[i] - nt[c])
+            dis = F(t * t)
+            if dis < best:
+                best, arg = dis, c
+        ncodes[i] = arg & 0xff
+    return codes, ncodes, norms
+
+
+def _fma_chain(a, x):
+    """acc = fmaf(a[k], x[k], acc) for k = 0..: one rounding per step, evaluated in float64 (exact product of two
+    float32 fits; the sum of a float32 and that product rounds to float32 correctly via float64 except in
+    double-rounding corner cases, which the assertion below would expose)."""
+    acc = F(0.0)
+    for k in range(len(a)):
+        acc = F(np.float64(a[k]) * np.float64(x[k]) + np.float64(acc))
+    return acc
+
+
+@pytest.mark.parametrize("d,M,opq", [(32, 4, False), (32, 8, True), (48, 8, False)])
+def test_add_batch_encode_matches_numpy_model(d, M, opq):
+    rng = np.random.default_rng(400 + d + M)
+    nc, n = 40, 24
+    cents = synth.sift_like(rng, nc, d)
+    graph = orc.Hnsw.build(cents, M=4, efConstruction=20)
+    cb = rng.normal(0, 9.0, size=(M, 256, d // M)).astype(F)
+    nt = np.sort(rng.normal(d * 2100.0, d * 300.0, size=256)).astype(F)
+    A = synth.random_rotation(rng, d) if opq else None
+    ox = orc.Index(d, M, graph, cb, nt, np.zeros(nc + 1, np.uint64), np.zeros(0, np.uint32), np.zeros((0, M), np.uint8),
+                   np.zeros(0, np.uint8), np.zeros(nc, F), opq_A=A)
+    ox.set_params(1, 0, 30)
+    x = (cents[rng.choice(nc, n)] + rng.normal(0, 15.0, size=(n, d))).astype(F)
+    idx, codes, ncodes, norms = ox.add_batch_encode(x)
+    # assign = searchKnn(x, 1) with efSearch (IndexIVF_HNSW.cpp:68-72)
+    for i in range(n):
+        rid, _ = graph.search_knn(x[i], 30, 1)
+        assert idx[i] == rid[0]
+    mc, mn, mnorm = np_add_batch_encode(x, idx, cents, cb, nt, A)
+    assert np.array_equal(codes, mc)
+    assert np.array_equal(norms.view(np.uint32), mnorm.view(np.uint32))
+    assert np.array_equal(ncodes, mn)
+    # supplied assignments take the other branch (:79-80)
+    pre = rng.integers(0, nc, size=n).astype(np.uint32)
+    idx2, codes2, ncodes2, _ = ox.add_batch_encode(x, pre)
+    mc2, mn2, _ = np_add_batch_encode(x, pre, cents, cb, nt, A)
+    assert np.array_equal(idx2, pre) and np.array_equal(codes2, mc2) and np.array_equal(ncodes2, mn2)
