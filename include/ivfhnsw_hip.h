@@ -170,6 +170,23 @@ int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, con
 int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t *precomputed_idx, size_t efSearch,
                        uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes);
 
+/* ivfhnsw_gpu_encode_groups replaces IndexIVF_HNSW_Grouping::add_group (IndexIVF_HNSW_Grouping.cpp:43-125, up to
+ * the distribution loops) for ngroups groups at once; group g is centroid centroid_idx[g] with the points
+ * x[offsets[g] .. offsets[g+1]) (host pointers, offsets[0] = 0).  Per group:
+ *   nn_centroid_idxs = searchKnn(centroid, nsubc + 1) with efSearch, minus the nearest          (:47-62)
+ *   alpha            = compute_alpha over the group's points                                    (:691-733)
+ *   sub-centroid s   = centroid + alpha * (neighbour_s - centroid)                              (:70-87)
+ *   subcentroid_idx  = first nearest sub-centroid of every point                                (:673-689)
+ *   codes, norm_codes as in ivfhnsw_gpu_encode with the sub-centroid in place of the centroid   (:93-125)
+ * out_nn_centroid_idxs [ngroups*nsubc]; out_alphas [ngroups] (written only for groups with points: an empty
+ * group keeps the caller's value, :63-64); out_subcentroid_idxs [n]; out_codes [n*code_size]; out_norm_codes [n].
+ * The caller lays each list out sub-group by sub-group in arrival order and records the sub-group sizes
+ * (:127-155).  Needs efSearch >= nsubc + 1; a walk that finds fewer centroids is an error. */
+int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, const uint32_t *centroid_idx,
+                              const uint64_t *offsets, const float *x, size_t efSearch, uint32_t *out_nn_centroid_idxs,
+                              float *out_alphas, uint32_t *out_subcentroid_idxs, uint8_t *out_codes,
+                              uint8_t *out_norm_codes);
+
 
 enum ivfhnsw_stage {
     IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */

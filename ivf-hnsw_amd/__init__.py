@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
+    "ivfhnsw_gpu_encode_groups",
 )
 
 
@@ -87,6 +88,8 @@ def lib():
         L.ivfhnsw_gpu_upload_codebooks.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                          C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_encode_groups.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_get_stage_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
@@ -253,6 +256,24 @@ class GpuIndex:
         ncodes = np.empty(n, np.uint8)
         _check(lib().ivfhnsw_gpu_encode(self._h, n, _ptr(x), _ptr(pidx), efSearch, _ptr(idx), _ptr(codes), _ptr(ncodes)))
         return idx, codes, ncodes
+
+    def encode_groups(self, nsubc, centroid_idx, offsets, x, efSearch, alphas_in=None):
+        """IndexIVF_HNSW_Grouping::add_group for many groups (Grouping.cpp:43-125):
+        (nn_centroid_idxs [G, nsubc], alphas [G], subcentroid_idxs [n], codes [n, M], norm_codes [n])."""
+        cidx = _np(centroid_idx, np.uint32)
+        off = _np(offsets, np.uint64)
+        G = cidx.shape[0]
+        x = _np(x, np.float32)
+        x = x.reshape(-1, x.shape[-1]) if x.size else x.reshape(0, 1)
+        n = int(off[-1])
+        nn = np.empty((G, nsubc), np.uint32)
+        alphas = np.zeros(G, np.float32) if alphas_in is None else _np(alphas_in, np.float32).copy()
+        sub = np.empty(n, np.uint32)
+        codes = np.empty((n, self._enc_M), np.uint8)
+        ncodes = np.empty(n, np.uint8)
+        _check(lib().ivfhnsw_gpu_encode_groups(self._h, G, nsubc, _ptr(cidx), _ptr(off), _ptr(x), efSearch, _ptr(nn),
+                                               _ptr(alphas), _ptr(sub), _ptr(codes), _ptr(ncodes)))
+        return nn, alphas, sub, codes, ncodes
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

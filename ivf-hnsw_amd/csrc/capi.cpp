@@ -90,6 +90,7 @@ struct ivfhnsw_gpu {
     bool has_graph = false;
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
     DevBuf e_pqc, e_ntab, e_a, e_at, e_x, e_idx, e_dist, e_res, e_tmp, e_codes, e_ncodes;
+    DevBuf cg_q, cg_cidx, cg_ids, cg_dists, gc_nn, cg_cvn, cg_tab, cg_tab2, cg_off, cg_alpha2, cg_sub; // add_group
     size_t e_d = 0, e_M = 0;
     bool e_opq = false, has_codebooks = false;
 
@@ -285,7 +286,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 3; }
+int ivfhnsw_gpu_abi_version(void) { return 4; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
@@ -333,7 +334,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
@@ -703,6 +704,32 @@ int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, con
     return IVFHNSW_OK;
 }
 
+// residual against table[rows[i]] -> [OPQ] -> codes -> decode -> [OPQ back] -> + table row -> squared norm -> norm
+// code, for m vectors in dx (clobbered).  Leaves the bytes in e_codes / e_ncodes.  The table is the centroid
+// table (add_batch) or a batch's sub-centroid table (add_group).
+static int encode_rows(ivfhnsw_gpu *h, size_t m, float *dx, const float *table, const uint32_t *rows)
+{
+    const size_t d = h->e_d, M = h->e_M;
+    float *res = h->e_res.as<float>(), *tmp = h->e_tmp.as<float>();
+    HIP_TRY(launch_madd_rows(h->stream, dx, -1.f, table, rows, res, m, (int)d));
+    const float *enc_in = res;
+    if (h->e_opq) {
+        HIP_TRY(launch_opq(h->stream, h->e_at.as<float>(), res, tmp, (int)m, (int)d));
+        enc_in = tmp;
+    }
+    HIP_TRY(launch_pq_encode(h->stream, enc_in, h->e_pqc.as<float>(), h->e_codes.as<uint8_t>(), m, (int)d, (int)M));
+    float *dec = h->e_opq ? res : tmp; // the buffer the encoder did not read
+    HIP_TRY(launch_pq_decode(h->stream, h->e_codes.as<uint8_t>(), h->e_pqc.as<float>(), dec, m, (int)d, (int)M));
+    float *back = dec;
+    if (h->e_opq) {
+        HIP_TRY(launch_opq(h->stream, h->e_a.as<float>(), dec, tmp, (int)m, (int)d));
+        back = tmp;
+    }
+    HIP_TRY(launch_madd_rows(h->stream, back, 1.f, table, rows, dx, m, (int)d)); // x is spent: reuse
+    HIP_TRY(launch_norm_codes(h->stream, dx, h->e_ntab.as<float>(), h->e_ncodes.as<uint8_t>(), nullptr, m, (int)d));
+    return IVFHNSW_OK;
+}
+
 int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t *precomputed_idx, size_t efSearch,
                        uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes)
 {
@@ -728,7 +755,7 @@ int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t 
             (rc = h->e_dist.ensure(m * sizeof(float))) || (rc = h->e_codes.ensure(m * M)) ||
             (rc = h->e_ncodes.ensure(m)))
             return rc;
-        float *dx = h->e_x.as<float>(), *res = h->e_res.as<float>(), *tmp = h->e_tmp.as<float>();
+        float *dx = h->e_x.as<float>();
         uint32_t *idx = h->e_idx.as<uint32_t>();
         HIP_TRY(hipMemcpyAsync(dx, x + i0 * d, m * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
         if (precomputed_idx) {
@@ -740,24 +767,8 @@ int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t 
         } else if ((rc = ivfhnsw_gpu_coarse_dev(h, m, dx, 1, efSearch, idx, h->e_dist.as<float>()))) {
             return rc;
         }
-        // residual = x - centroid[idx]; with OPQ the code is taken of A * residual
-        HIP_TRY(launch_madd_rows(h->stream, dx, -1.f, h->gr.vectors, idx, res, m, (int)d));
-        const float *enc_in = res;
-        if (h->e_opq) {
-            HIP_TRY(launch_opq(h->stream, h->e_at.as<float>(), res, tmp, (int)m, (int)d));
-            enc_in = tmp;
-        }
-        HIP_TRY(launch_pq_encode(h->stream, enc_in, h->e_pqc.as<float>(), h->e_codes.as<uint8_t>(), m, (int)d, (int)M));
-        // decode -> rotate back -> + centroid -> squared norm -> norm code
-        float *dec = h->e_opq ? res : tmp; // the buffer the encoder did not read
-        HIP_TRY(launch_pq_decode(h->stream, h->e_codes.as<uint8_t>(), h->e_pqc.as<float>(), dec, m, (int)d, (int)M));
-        float *back = dec;
-        if (h->e_opq) {
-            HIP_TRY(launch_opq(h->stream, h->e_a.as<float>(), dec, tmp, (int)m, (int)d));
-            back = tmp;
-        }
-        HIP_TRY(launch_madd_rows(h->stream, back, 1.f, h->gr.vectors, idx, dx, m, (int)d)); // x is spent: reuse
-        HIP_TRY(launch_norm_codes(h->stream, dx, h->e_ntab.as<float>(), h->e_ncodes.as<uint8_t>(), nullptr, m, (int)d));
+        if ((rc = encode_rows(h, m, dx, h->gr.vectors, idx)))
+            return rc;
         HIP_TRY(hipMemcpyAsync(out_codes + i0 * M, h->e_codes.p, m * M, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(out_norm_codes + i0, h->e_ncodes.p, m, hipMemcpyDeviceToHost, h->stream));
         if (out_idx)
@@ -765,6 +776,128 @@ int ivfhnsw_gpu_encode(ivfhnsw_gpu *h, size_t n, const float *x, const uint32_t 
         HIP_TRY(hipStreamSynchronize(h->stream));
         if ((rc = check_status(h)))
             return rc;
+    }
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, const uint32_t *centroid_idx,
+                              const uint64_t *offsets, const float *x, size_t efSearch, uint32_t *out_nn_centroid_idxs,
+                              float *out_alphas, uint32_t *out_subcentroid_idxs, uint8_t *out_codes,
+                              uint8_t *out_norm_codes)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_codebooks || !h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "encode_groups needs upload_codebooks and upload_quantizer");
+    if ((size_t)h->gr.d != h->e_d)
+        return fail(IVFHNSW_ERR_STATE, "code books are for d = %zu, the quantizer holds d = %d", h->e_d, h->gr.d);
+    if (ngroups == 0)
+        return IVFHNSW_OK;
+    if (!centroid_idx || !offsets || !out_nn_centroid_idxs || !out_alphas)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer");
+    const size_t d = h->e_d, M = h->e_M, k = nsubc + 1;
+    if (nsubc == 0 || nsubc > 4096 || efSearch < k || k > h->gr.n)
+        return fail(IVFHNSW_ERR_INVALID, "nsubc %zu: need 1 <= nsubc, nsubc + 1 <= efSearch (%zu) and <= %u centroids",
+                    nsubc, efSearch, h->gr.n);
+    if (group_points_lds_bytes((int)nsubc, (int)d) > 160 * 1024)
+        return fail(IVFHNSW_ERR_INVALID, "nsubc %zu x d %zu does not fit the 160 KB of LDS of one workgroup", nsubc, d);
+    if (offsets[0] != 0)
+        return fail(IVFHNSW_ERR_INVALID, "offsets[0] must be 0");
+    const uint64_t n_total = offsets[ngroups];
+    for (size_t g = 0; g < ngroups; g++) {
+        if (offsets[g + 1] < offsets[g])
+            return fail(IVFHNSW_ERR_INVALID, "offsets not monotone at group %zu", g);
+        if (centroid_idx[g] >= h->gr.n)
+            return fail(IVFHNSW_ERR_INVALID, "centroid_idx[%zu] = %u out of range", g, centroid_idx[g]);
+    }
+    if (n_total && (!x || !out_subcentroid_idxs || !out_codes || !out_norm_codes))
+        return fail(IVFHNSW_ERR_INVALID, "null buffer");
+    // chunks of whole groups: at most 2^18 points (one oversized group goes alone) and 4096 groups
+    const size_t kMaxPoints = (size_t)1 << 18, kMaxGroups = 4096;
+    std::vector<uint32_t> ids, nn;
+    std::vector<float> dists, cvn;
+    std::vector<unsigned long long> off;
+    for (size_t g0 = 0; g0 < ngroups;) {
+        size_t g1 = g0 + 1;
+        while (g1 < ngroups && g1 - g0 < kMaxGroups && offsets[g1 + 1] - offsets[g0] <= kMaxPoints)
+            g1++;
+        const size_t G = g1 - g0, p0 = offsets[g0], m = offsets[g1] - p0;
+        // neighbour centroids: searchKnn(centroid, nsubc + 1) for every group of the chunk (Grouping.cpp:47-62)
+        if ((rc = h->cg_q.ensure(G * d * sizeof(float))) || (rc = h->cg_cidx.ensure(G * sizeof(uint32_t))) ||
+            (rc = h->cg_ids.ensure(G * k * sizeof(uint32_t))) || (rc = h->cg_dists.ensure(G * k * sizeof(float))) ||
+            (rc = h->gc_nn.ensure(G * nsubc * sizeof(uint32_t))) || (rc = h->cg_cvn.ensure(G * nsubc * sizeof(float))) ||
+            (rc = h->cg_tab.ensure(G * nsubc * d * sizeof(float))) || (rc = h->cg_tab2.ensure(G * nsubc * d * sizeof(float))) ||
+            (rc = h->cg_off.ensure((G + 1) * sizeof(unsigned long long))) || (rc = h->cg_alpha2.ensure(G * sizeof(float))))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(h->cg_cidx.p, centroid_idx + g0, G * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(h->cg_q.p, 0, G * d * sizeof(float), h->stream));
+        HIP_TRY(launch_madd_rows(h->stream, h->cg_q.as<float>(), 1.f, h->gr.vectors, h->cg_cidx.as<uint32_t>(),
+                                 h->cg_q.as<float>(), G, (int)d)); // 0 + 1 * row: the centroid rows as queries
+        if ((rc = ivfhnsw_gpu_coarse_dev(h, G, h->cg_q.as<float>(), k, efSearch, h->cg_ids.as<uint32_t>(),
+                                         h->cg_dists.as<float>())))
+            return rc;
+        ids.resize(G * k);
+        dists.resize(G * k);
+        HIP_TRY(hipMemcpyAsync(ids.data(), h->cg_ids.p, G * k * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(dists.data(), h->cg_dists.p, G * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if ((rc = check_status(h)))
+            return rc;
+        nn.resize(G * nsubc);
+        cvn.resize(G * nsubc);
+        for (size_t g = 0; g < G; g++)
+            for (size_t s = 0; s < nsubc; s++) { // the nearest one (the centroid itself) is dropped
+                if (ids[g * k + s + 1] == 0xffffffffu)
+                    return fail(IVFHNSW_ERR_INVALID, "group %zu: the walk found fewer than nsubc + 1 = %zu centroids "
+                                                     "(the reference leaves zero entries behind here)", g0 + g, k);
+                nn[g * nsubc + s] = ids[g * k + s + 1];
+                cvn[g * nsubc + s] = dists[g * k + s + 1];
+            }
+        std::memcpy(out_nn_centroid_idxs + g0 * nsubc, nn.data(), G * nsubc * sizeof(uint32_t));
+        if (m == 0) { // only empty groups: alpha stays what the caller has (Grouping.cpp:63-64)
+            g0 = g1;
+            continue;
+        }
+        off.resize(G + 1);
+        for (size_t g = 0; g <= G; g++)
+            off[g] = offsets[g0 + g] - p0;
+        if ((rc = h->e_x.ensure(m * d * sizeof(float))) || (rc = h->e_res.ensure(m * d * sizeof(float))) ||
+            (rc = h->e_tmp.ensure(m * d * sizeof(float))) || (rc = h->e_idx.ensure(m * sizeof(uint32_t))) ||
+            (rc = h->e_dist.ensure(2 * m * sizeof(float))) || (rc = h->e_codes.ensure(m * M)) ||
+            (rc = h->e_ncodes.ensure(m)) || (rc = h->cg_sub.ensure(m * sizeof(uint32_t))))
+            return rc;
+        float *dx = h->e_x.as<float>();
+        HIP_TRY(hipMemcpyAsync(dx, x + p0 * d, m * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->gc_nn.p, nn.data(), G * nsubc * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->cg_cvn.p, cvn.data(), G * nsubc * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->cg_off.p, off.data(), (G + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+        const uint32_t *cidx = h->cg_cidx.as<uint32_t>();
+        const unsigned long long *doff = h->cg_off.as<unsigned long long>();
+        float *cv = h->cg_tab.as<float>(), *sub = h->cg_tab2.as<float>(), *num = h->e_dist.as<float>(), *den = num + m;
+        HIP_TRY(launch_group_table(h->stream, 0, h->gr.vectors, cidx, (const uint32_t *)h->gc_nn.p, nullptr, nullptr, cv, G,
+                                   (int)nsubc, (int)d));
+        HIP_TRY(launch_group_points(h->stream, 0, h->gr.vectors, cidx, cv, h->cg_cvn.as<float>(), doff, dx, num, den,
+                                    nullptr, G, (int)nsubc, (int)d));
+        HIP_TRY(launch_group_alpha(h->stream, doff, num, den, h->cg_alpha2.as<float>(), G));
+        HIP_TRY(launch_group_table(h->stream, 1, h->gr.vectors, cidx, nullptr, h->cg_alpha2.as<float>(), cv, sub, G,
+                                   (int)nsubc, (int)d));
+        HIP_TRY(launch_group_points(h->stream, 1, h->gr.vectors, cidx, sub, nullptr, doff, dx, nullptr, nullptr,
+                                    h->cg_sub.as<uint32_t>(), G, (int)nsubc, (int)d));
+        HIP_TRY(launch_group_rows(h->stream, doff, h->cg_sub.as<uint32_t>(), h->e_idx.as<uint32_t>(), G, (int)nsubc));
+        if ((rc = encode_rows(h, m, dx, sub, h->e_idx.as<uint32_t>())))
+            return rc;
+        // alphas: only groups with points are written (an empty group keeps the caller's value)
+        std::vector<float> al(G);
+        HIP_TRY(hipMemcpyAsync(al.data(), h->cg_alpha2.p, G * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out_subcentroid_idxs + p0, h->cg_sub.p, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out_codes + p0 * M, h->e_codes.p, m * M, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(out_norm_codes + p0, h->e_ncodes.p, m, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t g = 0; g < G; g++)
+            if (off[g + 1] > off[g])
+                out_alphas[g0 + g] = al[g];
+        g0 = g1;
     }
     return IVFHNSW_OK;
 }
@@ -1046,7 +1179,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

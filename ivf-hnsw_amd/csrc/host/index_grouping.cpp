@@ -1,7 +1,7 @@
 // ivfhnsw::IndexIVF_HNSW_Grouping over the MI355X C ABI (include/ivf-hnsw/IndexIVF_HNSW_Grouping.h).
 // search runs on the device (plan_grouping_kernel + the ADC scan); read/write keep the reference's Grouping
 // .index layout (IndexIVF_HNSW_Grouping.cpp:397-483).  add_group / train_pq (index construction) are outside
-// the search path and not implemented yet.
+// the search path; add_group runs on the device, code book training is not built.
 #include <ivf-hnsw/IndexIVF_HNSW_Grouping.h>
 
 #include <ivfhnsw_hip.h>
@@ -186,32 +186,119 @@ void IndexIVF_HNSW_Grouping::dump_inter_centroid_dists(char *path)
     fclose(fp);
 }
 
-// ---- index construction: not part of the search path ---------------------------------
+// ---- index construction -------------------------------------------------------------------
+// add_group: everything up to the distribution loops (Grouping.cpp:43-125) is one device call; the sub-group
+// layout of the list (:127-155) stays here.
+void IndexIVF_HNSW_Grouping::add_group(size_t centroid_idx, size_t group_size, const float *data, const idx_t *idxs)
+{
+    ensure_encoder();
+    const uint32_t cidx = (uint32_t)centroid_idx;
+    const uint64_t off[2] = {0, (uint64_t)group_size};
+    nn_centroid_idxs[centroid_idx].resize(nsubc);
+    std::vector<idx_t> sub(group_size);
+    std::vector<uint8_t> xcodes(group_size * code_size), xnorm(group_size);
+    float alpha = alphas[centroid_idx];
+    if (ivfhnsw_gpu_encode_groups(gpu_, 1, nsubc, &cidx, off, data, quantizer->efSearch,
+                                  nn_centroid_idxs[centroid_idx].data(), &alpha, sub.data(), xcodes.data(), xnorm.data()))
+        throw std::runtime_error(std::string("ivfhnsw_gpu_encode_groups: ") + ivfhnsw_gpu_last_error());
+    if (group_size == 0)
+        return; // :63-64: neighbours recorded, nothing else
+    alphas[centroid_idx] = alpha;
+    std::vector<std::vector<size_t>> members(nsubc); // arrival order inside every sub-group
+    for (size_t i = 0; i < group_size; i++)
+        members[sub[i]].push_back(i);
+    for (size_t s = 0; s < nsubc; s++) {
+        subgroup_sizes[centroid_idx].push_back((idx_t)members[s].size());
+        for (size_t i : members[s]) {
+            ids[centroid_idx].push_back(idxs[i]);
+            codes[centroid_idx].insert(codes[centroid_idx].end(), xcodes.begin() + i * code_size,
+                                       xcodes.begin() + (i + 1) * code_size);
+            norm_codes[centroid_idx].push_back(xnorm[i]);
+        }
+    }
+    device_dirty_ = true;
+}
+
 static void not_built(const char *what)
 {
     throw std::runtime_error(std::string("IndexIVF_HNSW_Grouping::") + what +
-                             ": Grouping index construction is outside the MI355X search path and not implemented "
-                             "yet (SURVEY.md 8f); load a built index with read()");
+                             ": code book training for the Grouping index is not implemented (SURVEY.md 8f rank 4); "
+                             "load trained code books with read_ProductQuantizer");
 }
 
-void IndexIVF_HNSW_Grouping::add_group(size_t, size_t, const float *, const idx_t *) { not_built("add_group"); }
 void IndexIVF_HNSW_Grouping::train_pq(size_t, const float *) { not_built("train_pq"); }
-void IndexIVF_HNSW_Grouping::compute_residuals(size_t, const float *, float *, const float *, const idx_t *)
+
+// The per-group helpers of the reference (:655-733) as host functions, for callers that use them directly; add_group
+// does not go through them.
+void IndexIVF_HNSW_Grouping::compute_residuals(size_t n, const float *x, float *residuals, const float *subcentroids,
+                                               const idx_t *keys)
 {
-    not_built("compute_residuals");
+    for (size_t i = 0; i < n; i++)
+        faiss::fvec_madd(d, x + i * d, -1.f, subcentroids + (size_t)keys[i] * d, residuals + i * d);
 }
-void IndexIVF_HNSW_Grouping::reconstruct(size_t, float *, const float *, const float *, const idx_t *)
+
+void IndexIVF_HNSW_Grouping::reconstruct(size_t n, float *x, const float *decoded_residuals, const float *subcentroids,
+                                         const idx_t *keys)
 {
-    not_built("reconstruct");
+    for (size_t i = 0; i < n; i++)
+        faiss::fvec_madd(d, decoded_residuals + i * d, 1.f, subcentroids + (size_t)keys[i] * d, x + i * d);
 }
-void IndexIVF_HNSW_Grouping::compute_subcentroid_idxs(idx_t *, const float *, const float *, size_t)
+
+void IndexIVF_HNSW_Grouping::compute_subcentroid_idxs(idx_t *subcentroid_idxs, const float *subcentroids,
+                                                      const float *x, size_t group_size)
 {
-    not_built("compute_subcentroid_idxs");
+    for (size_t i = 0; i < group_size; i++) {
+        float min_dist = 0.f;
+        long min_idx = -1;
+        for (size_t s = 0; s < nsubc; s++) {
+            const float dist = fvec_L2sqr(subcentroids + s * d, x + i * d, d);
+            if (min_idx == -1 || dist < min_dist) {
+                min_dist = dist;
+                min_idx = (long)s;
+            }
+        }
+        subcentroid_idxs[i] = (idx_t)min_idx;
+    }
 }
-float IndexIVF_HNSW_Grouping::compute_alpha(const float *, const float *, const float *, const float *, size_t)
+
+float IndexIVF_HNSW_Grouping::compute_alpha(const float *centroid_vectors, const float *points, const float *centroid,
+                                            const float *centroid_vector_norms_L2sqr, size_t group_size)
 {
-    not_built("compute_alpha");
-    return 0.f;
+    float group_numerator = 0.f, group_denominator = 0.f;
+    std::vector<float> pv(d), sub(d);
+    for (size_t i = 0; i < group_size; i++) {
+        const float *point = points + i * d;
+        faiss::fvec_madd(d, point, -1.f, centroid, pv.data());
+        bool have = false;
+        float bneg = 0.f, bnum = 0.f, bden = 0.f;
+        for (size_t s = 0; s < nsubc; s++) {
+            const float *cv = centroid_vectors + s * d;
+            float numerator = faiss::fvec_inner_product(cv, pv.data(), d);
+            numerator = numerator > 0 ? numerator : 0.f;
+            const float denominator = centroid_vector_norms_L2sqr[s];
+            faiss::fvec_madd(d, centroid, numerator / denominator, cv, sub.data());
+            const float neg = -fvec_L2sqr(point, sub.data(), d);
+            // top of the reference's max-heap of pair<-dist, pair<numerator, denominator>>; a NaN never wins
+            bool better;
+            if (!have)
+                better = true;
+            else if (neg != neg)
+                better = false;
+            else if (bneg != bneg)
+                better = true;
+            else
+                better = bneg < neg || (!(neg < bneg) && (bnum < numerator || (!(numerator < bnum) && bden < denominator)));
+            if (better) {
+                have = true;
+                bneg = neg;
+                bnum = numerator;
+                bden = denominator;
+            }
+        }
+        group_numerator += bnum;
+        group_denominator += bden;
+    }
+    return group_denominator > 0 ? group_numerator / group_denominator : 0.f;
 }
 
 } // namespace ivfhnsw

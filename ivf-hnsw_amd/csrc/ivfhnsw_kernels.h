@@ -121,6 +121,19 @@ hipError_t launch_pq_encode(hipStream_t s, const float *r, const float *cb, uint
 hipError_t launch_pq_decode(hipStream_t s, const uint8_t *codes, const float *cb, float *dec, size_t n, int d, int M);
 hipError_t launch_norm_codes(hipStream_t s, const float *rec, const float *ntab, uint8_t *norm_codes, float *norms_out,
                              size_t n, int d);
+// Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-157)
+hipError_t launch_group_table(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
+                              const uint32_t *nn, const float *alphas, const float *cv_in, float *out, size_t ngroups,
+                              int nsubc, int d);
+size_t group_points_lds_bytes(int nsubc, int d);
+hipError_t launch_group_points(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
+                               const float *table, const float *cv_norms, const unsigned long long *offsets,
+                               const float *x, float *out_num, float *out_den, uint32_t *out_sub, size_t ngroups,
+                               int nsubc, int d);
+hipError_t launch_group_alpha(hipStream_t s, const unsigned long long *offsets, const float *num, const float *den,
+                              float *alphas, size_t ngroups);
+hipError_t launch_group_rows(hipStream_t s, const unsigned long long *offsets, const uint32_t *sub, uint32_t *rows,
+                             size_t ngroups, int nsubc);
 // nbrows[i][j] = qrows[links[i][j]] for j < counts[i], zero otherwise (GraphTables::nbrows)
 hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows);
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);

@@ -20,10 +20,8 @@ namespace {
 
 // c = a + bf * b per element (faiss::fvec_madd), bf = -1: residual, bf = +1: reconstruction.
 // b is row idx[i] of the centroid table.
-__global__ __launch_bounds__(256) void madd_rows_kernel(const float *__restrict__ a, float bf,
-                                                        const float *__restrict__ table,
-                                                        const uint32_t *__restrict__ idx, float *__restrict__ c,
-                                                        size_t n, int d)
+__global__ __launch_bounds__(256) void madd_rows_kernel(const float *a, float bf, const float *__restrict__ table,
+                                                        const uint32_t *__restrict__ idx, float *c, size_t n, int d)
 {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n * (size_t)d)
@@ -160,6 +158,242 @@ __global__ __launch_bounds__(256) void norm_code_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-157).  Per group: cv[s] = neighbour_s - centroid, alpha,
+// sub-centroids centroid + alpha * cv[s], every point's nearest sub-centroid; the code bytes then come from the
+// same kernels as above with the sub-centroid table in place of the centroid table.
+
+// cv[g][s][:] = vectors[nn[g][s]] + (-1 * centroid_g)   (fvec_madd, :70-74)      MODE 0
+// sub[g][s][:] = centroid_g + alpha_g * cv[g][s][:]      (fvec_madd, :82-87)      MODE 1
+template <int MODE>
+__global__ __launch_bounds__(256) void group_table_kernel(const float *__restrict__ vectors,
+                                                          const uint32_t *__restrict__ centroid_idx,
+                                                          const uint32_t *__restrict__ nn, const float *__restrict__ alphas,
+                                                          const float *__restrict__ cv_in, float *__restrict__ out,
+                                                          size_t ngroups, int nsubc, int d)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)nsubc * d;
+    if (e >= ngroups * per)
+        return;
+    const size_t g = e / per;
+    const int j = (int)(e % (size_t)d);
+    const float c = vectors[(size_t)centroid_idx[g] * d + j];
+    if (MODE == 0) {
+        const int sidx = (int)((e - g * per) / (size_t)d);
+        out[e] = __fadd_rn(vectors[(size_t)nn[g * nsubc + sidx] * d + j], __fmul_rn(-1.f, c));
+    } else {
+        out[e] = __fadd_rn(c, __fmul_rn(alphas[g], cv_in[e]));
+    }
+}
+
+// ivfhnsw::fvec_L2sqr (utils.cpp:22-52) between x[] (LDS, row p) and y[] computed on the fly: lane-free form,
+// eight accumulators, element j goes to accumulator j % 8 in increasing j, dims beyond a multiple of 16 ignored,
+// accumulators summed left to right.
+struct L2Avx8 {
+    float a[8];
+    __device__ __forceinline__ void init()
+    {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            a[k] = 0.f;
+    }
+    __device__ __forceinline__ float sum() const
+    {
+        float r = __fadd_rn(a[0], a[1]);
+#pragma unroll
+        for (int k = 2; k < 8; k++)
+            r = __fadd_rn(r, a[k]);
+        return r;
+    }
+};
+
+// Does candidate (neg, num, den) displace the best so far?  The reference keeps the top of a max-heap of
+// pair<-dist, pair<numerator, denominator>> (std::pair order); a NaN distance never displaces anything and is
+// displaced by anything.  Written without branches on purpose: the nested if/else form of this test inside
+// the candidate loop was miscompiled by hipcc 7.2 for gfx950 (the distance of a share's second candidate was
+// dropped while its numerator was kept; adding a printf to the loop made it correct), see DESIGN.md 3.4.
+__device__ __forceinline__ bool alpha_cand_better(bool have, float bneg, float bnum, float bden, float neg, float num,
+                                                  float den)
+{
+    const bool ok = neg == neg, bok = bneg == bneg;
+    const bool lt = bneg < neg;
+    const bool eq = !(neg < bneg) & !lt;
+    const bool second = (bnum < num) | (!(num < bnum) & (bden < den));
+    return !have | (ok & (!bok | lt | (eq & second)));
+}
+
+// One block per group, 64 points per tile, thread = (point, quarter of the sub-centroids).
+//  MODE 0 (compute_alpha, :691-733): table = cv; per point the (numerator, denominator) of the candidate
+//          sub-centroid centroid + (max(<cv,pv>,0)/norm) * cv closest to the point (ties: larger numerator,
+//          then denominator -- std::pair order of the reference's max-heap).
+//  MODE 1 (compute_subcentroid_idxs, :673-689): table = sub-centroids; first minimum of the distance.
+template <int MODE>
+__global__ __launch_bounds__(256) void group_points_kernel(const float *__restrict__ vectors,
+                                                           const uint32_t *__restrict__ centroid_idx,
+                                                           const float *__restrict__ table, // [G][nsubc][d]
+                                                           const float *__restrict__ cv_norms, // [G][nsubc] (MODE 0)
+                                                           const unsigned long long *__restrict__ offsets,
+                                                           const float *__restrict__ x, float *__restrict__ out_num,
+                                                           float *__restrict__ out_den, uint32_t *__restrict__ out_sub,
+                                                           int nsubc, int d)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem_g[];
+    const int ld = d + 1;
+    float *s_tab = smem_g;                     // [nsubc][ld]
+    float *s_x = s_tab + (size_t)nsubc * ld;   // [64][ld]
+    float *s_c = s_x + (size_t)64 * ld;        // [d]
+    float *s_n = s_c + d;                      // [nsubc]
+    float *s_r0 = s_n + nsubc;                 // [256] reduction scratch
+    float *s_r1 = s_r0 + 256;
+    float *s_r2 = s_r1 + 256;
+    const size_t g = blockIdx.x;
+    const size_t p0 = offsets[g], p1 = offsets[g + 1];
+    if (p0 == p1)
+        return;
+    for (int e = threadIdx.x; e < nsubc * d; e += 256)
+        s_tab[(e / d) * ld + (e % d)] = table[g * (size_t)nsubc * d + e];
+    for (int e = threadIdx.x; e < d; e += 256)
+        s_c[e] = vectors[(size_t)centroid_idx[g] * d + e];
+    if (MODE == 0)
+        for (int e = threadIdx.x; e < nsubc; e += 256)
+            s_n[e] = cv_norms[g * (size_t)nsubc + e];
+    const int p = threadIdx.x & 63, qtr = threadIdx.x >> 6;
+    const int s_lo = (nsubc * qtr) / 4, s_hi = (nsubc * (qtr + 1)) / 4;
+    const int d16 = d & ~15;
+    for (size_t t0 = p0; t0 < p1; t0 += 64) {
+        __syncthreads();
+        const int np = (int)((p1 - t0) < 64 ? (p1 - t0) : 64);
+        for (int e = threadIdx.x; e < np * d; e += 256)
+            s_x[(e / d) * ld + (e % d)] = x[t0 * (size_t)d + e];
+        __syncthreads();
+        // per-thread best over its share of the sub-centroids
+        bool have = false;
+        float bneg = 0.f, bnum = 0.f, bden = 0.f; // MODE 0
+        float bdist = 0.f;                        // MODE 1
+        int bs = 0;
+        if (p < np) {
+            const float *xr = s_x + p * ld;
+            for (int sc = s_lo; sc < s_hi; sc++) {
+                const float *tr = s_tab + sc * ld;
+                if (MODE == 0) {
+                    // numerator = faiss::fvec_inner_product(cv, pv) with pv = x + (-1 * centroid): SSE order
+                    float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+                    int j = 0;
+                    for (; j + 4 <= d; j += 4) {
+                        q0 = __fadd_rn(q0, __fmul_rn(tr[j], __fadd_rn(xr[j], __fmul_rn(-1.f, s_c[j]))));
+                        q1 = __fadd_rn(q1, __fmul_rn(tr[j + 1], __fadd_rn(xr[j + 1], __fmul_rn(-1.f, s_c[j + 1]))));
+                        q2 = __fadd_rn(q2, __fmul_rn(tr[j + 2], __fadd_rn(xr[j + 2], __fmul_rn(-1.f, s_c[j + 2]))));
+                        q3 = __fadd_rn(q3, __fmul_rn(tr[j + 3], __fadd_rn(xr[j + 3], __fmul_rn(-1.f, s_c[j + 3]))));
+                    }
+                    if (j < d)
+                        q0 = __fadd_rn(q0, __fmul_rn(tr[j], __fadd_rn(xr[j], __fmul_rn(-1.f, s_c[j]))));
+                    if (j + 1 < d)
+                        q1 = __fadd_rn(q1, __fmul_rn(tr[j + 1], __fadd_rn(xr[j + 1], __fmul_rn(-1.f, s_c[j + 1]))));
+                    if (j + 2 < d)
+                        q2 = __fadd_rn(q2, __fmul_rn(tr[j + 2], __fadd_rn(xr[j + 2], __fmul_rn(-1.f, s_c[j + 2]))));
+                    float num = __fadd_rn(__fadd_rn(q0, q1), __fadd_rn(q2, q3));
+                    num = num > 0.f ? num : 0.f;
+                    const float den = s_n[sc];
+                    const float al = num / den; // IEEE division: correctly rounded (no fast-math)
+                    L2Avx8 acc;
+                    acc.init();
+                    for (int b = 0; b < d16; b += 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const float sub = __fadd_rn(s_c[b + k], __fmul_rn(al, tr[b + k]));
+                            const float df = __fsub_rn(xr[b + k], sub);
+                            acc.a[k] = __fadd_rn(acc.a[k], __fmul_rn(df, df));
+                        }
+                    }
+                    const float neg = -acc.sum();
+                    const bool better = alpha_cand_better(have, bneg, bnum, bden, neg, num, den);
+                    have = true;
+                    bneg = better ? neg : bneg;
+                    bnum = better ? num : bnum;
+                    bden = better ? den : bden;
+                } else {
+                    L2Avx8 acc;
+                    acc.init();
+                    for (int b = 0; b < d16; b += 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const float df = __fsub_rn(tr[b + k], xr[b + k]);
+                            acc.a[k] = __fadd_rn(acc.a[k], __fmul_rn(df, df));
+                        }
+                    }
+                    const float dist = acc.sum();
+                    const bool take = !have | (dist < bdist); // first minimum inside this share (increasing sc)
+                    have = true;
+                    bdist = take ? dist : bdist;
+                    bs = take ? sc : bs;
+                }
+            }
+        }
+        // fold the four shares of a point in increasing order of sub-centroid index (= the serial loop's order)
+        s_r0[threadIdx.x] = MODE == 0 ? bneg : bdist;
+        s_r1[threadIdx.x] = MODE == 0 ? bnum : __int_as_float(bs);
+        s_r2[threadIdx.x] = MODE == 0 ? bden : (have ? 1.f : 0.f);
+        __syncthreads();
+        if (qtr == 0 && p < np) {
+            if (MODE == 0) {
+                float fneg = bneg, fnum = bnum, fden = bden;
+                bool fhave = have;
+                for (int k = 1; k < 4; k++) {
+                    if (((nsubc * (k + 1)) / 4) == ((nsubc * k) / 4))
+                        continue; // empty share
+                    const float neg = s_r0[k * 64 + p], num = s_r1[k * 64 + p], den = s_r2[k * 64 + p];
+                    const bool better = alpha_cand_better(fhave, fneg, fnum, fden, neg, num, den);
+                    fhave = true;
+                    fneg = better ? neg : fneg;
+                    fnum = better ? num : fnum;
+                    fden = better ? den : fden;
+                }
+                out_num[t0 + p] = fnum;
+                out_den[t0 + p] = fden;
+            } else {
+                float fd = bdist;
+                int fs = bs;
+                bool fhave = have;
+                for (int k = 1; k < 4; k++) {
+                    if (s_r2[k * 64 + p] == 0.f)
+                        continue;
+                    const float dist = s_r0[k * 64 + p];
+                    const bool take = !fhave | (dist < fd);
+                    fhave = true;
+                    fs = take ? __float_as_int(s_r1[k * 64 + p]) : fs;
+                    fd = take ? dist : fd;
+                }
+                out_sub[t0 + p] = (uint32_t)fs;
+            }
+        }
+    }
+}
+
+// alpha_g = sum of the points' numerators / sum of their denominators, both added in point order (:724-727)
+__global__ void group_alpha_kernel(const unsigned long long *__restrict__ offsets, const float *__restrict__ num,
+                                   const float *__restrict__ den, float *__restrict__ alphas, size_t ngroups)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups)
+        return;
+    float a = 0.f, b = 0.f;
+    for (size_t i = offsets[g]; i < offsets[g + 1]; i++) {
+        a = __fadd_rn(a, num[i]);
+        b = __fadd_rn(b, den[i]);
+    }
+    alphas[g] = b > 0.f ? __fdiv_rn(a, b) : 0.f;
+}
+
+// table row of every point: g * nsubc + sub-centroid index
+__global__ void group_rows_kernel(const unsigned long long *__restrict__ offsets, const uint32_t *__restrict__ sub,
+                                  uint32_t *__restrict__ rows, size_t ngroups, int nsubc)
+{
+    const size_t g = blockIdx.x;
+    for (size_t i = offsets[g] + threadIdx.x; i < offsets[g + 1]; i += blockDim.x)
+        rows[i] = (uint32_t)(g * (size_t)nsubc + sub[i]);
+}
+
 } // namespace
 
 hipError_t launch_madd_rows(hipStream_t s, const float *a, float bf, const float *table, const uint32_t *idx, float *c,
@@ -212,6 +446,70 @@ hipError_t launch_norm_codes(hipStream_t s, const float *rec, const float *ntab,
         return hipSuccess;
     hipLaunchKernelGGL(norm_code_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, rec, ntab, norm_codes,
                        norms_out, n, d);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_table(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
+                              const uint32_t *nn, const float *alphas, const float *cv_in, float *out, size_t ngroups,
+                              int nsubc, int d)
+{
+    if (ngroups == 0)
+        return hipSuccess;
+    const size_t blocks = (ngroups * (size_t)nsubc * d + 255) / 256;
+    if (blocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    if (mode == 0)
+        hipLaunchKernelGGL(group_table_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, vectors, centroid_idx, nn,
+                           alphas, cv_in, out, ngroups, nsubc, d);
+    else
+        hipLaunchKernelGGL(group_table_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, vectors, centroid_idx, nn,
+                           alphas, cv_in, out, ngroups, nsubc, d);
+    return hipGetLastError();
+}
+
+size_t group_points_lds_bytes(int nsubc, int d)
+{
+    return ((size_t)(nsubc + 64) * (d + 1) + d + nsubc + 3 * 256) * sizeof(float);
+}
+
+hipError_t launch_group_points(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
+                               const float *table, const float *cv_norms, const unsigned long long *offsets,
+                               const float *x, float *out_num, float *out_den, uint32_t *out_sub, size_t ngroups,
+                               int nsubc, int d)
+{
+    if (ngroups == 0)
+        return hipSuccess;
+    const size_t shm = group_points_lds_bytes(nsubc, d);
+    if (shm > 160 * 1024 || ngroups > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    if (mode == 0) {
+        (void)hipFuncSetAttribute((const void *)group_points_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(group_points_kernel<0>, dim3((unsigned)ngroups), dim3(256), shm, s, vectors, centroid_idx,
+                           table, cv_norms, offsets, x, out_num, out_den, out_sub, nsubc, d);
+    } else {
+        (void)hipFuncSetAttribute((const void *)group_points_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(group_points_kernel<1>, dim3((unsigned)ngroups), dim3(256), shm, s, vectors, centroid_idx,
+                           table, cv_norms, offsets, x, out_num, out_den, out_sub, nsubc, d);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_group_alpha(hipStream_t s, const unsigned long long *offsets, const float *num, const float *den,
+                              float *alphas, size_t ngroups)
+{
+    if (ngroups == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(group_alpha_kernel, dim3((unsigned)((ngroups + 63) / 64)), dim3(64), 0, s, offsets, num, den,
+                       alphas, ngroups);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_rows(hipStream_t s, const unsigned long long *offsets, const uint32_t *sub, uint32_t *rows,
+                             size_t ngroups, int nsubc)
+{
+    if (ngroups == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(group_rows_kernel, dim3((unsigned)ngroups), dim3(256), 0, s, offsets, sub, rows, ngroups, nsubc);
     return hipGetLastError();
 }
 

@@ -1007,6 +1007,137 @@ void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const u
     }
 }
 
+/* IndexIVF_HNSW_Grouping.cpp:691-733 compute_alpha.  The per-point winner is maxheap.top() of
+ * pair<-dist, pair<numerator, denominator>>: smallest dist, ties to the larger numerator, then denominator. */
+static float grouping_compute_alpha(size_t d, size_t nsubc, const float *centroid_vectors, const float *points,
+                                    const float *centroid, const float *cv_norms, size_t group_size)
+{
+    float group_numerator = 0.0f, group_denominator = 0.0f;
+    float *pv = (float *)malloc(2 * d * sizeof(float)), *sub = pv + d;
+    for (size_t i = 0; i < group_size; i++) {
+        const float *point = points + i * d;
+        for (size_t j = 0; j < d; j++) /* :699-700 fvec_madd(d, point, -1, centroid, point_vector) */
+            pv[j] = point[j] + -1.0f * centroid[j];
+        int have = 0;
+        float bneg = 0.0f, bnum = 0.0f, bden = 0.0f;
+        for (size_t s = 0; s < nsubc; s++) {
+            const float *cv = centroid_vectors + s * d;
+            float numerator = orc_inner_product_sse_order(cv, pv, d); /* :711 */
+            numerator = (numerator > 0) ? numerator : 0.0f;          /* :712 */
+            const float denominator = cv_norms[s];
+            const float a = numerator / denominator;
+            for (size_t j = 0; j < d; j++) /* :718 fvec_madd(d, centroid, alpha, cv, subcentroid) */
+                sub[j] = centroid[j] + a * cv[j];
+            const float neg = -orc_l2sqr(point, sub, d); /* :720-721 */
+            int better;
+            if (!have)
+                better = 1;
+            else if (neg != neg)
+                better = 0; /* NaN never displaces anything */
+            else if (bneg != bneg)
+                better = 1;
+            else /* std::pair operator< on (neg, (num, den)) */
+                better = bneg < neg ||
+                         (!(neg < bneg) && (bnum < numerator || (!(numerator < bnum) && bden < denominator)));
+            if (better) {
+                have = 1;
+                bneg = neg;
+                bnum = numerator;
+                bden = denominator;
+            }
+        }
+        group_numerator += bnum; /* :724-725 */
+        group_denominator += bden;
+    }
+    free(pv);
+    return (group_denominator > 0) ? group_numerator / group_denominator : 0.0f; /* :727 */
+}
+
+int orc_add_group_encode(const orc_index *ix, size_t nsubc, uint32_t centroid_idx, size_t group_size,
+                         const float *data, uint32_t *nn_centroid_idxs, float *alpha, uint32_t *subcentroid_idxs,
+                         uint8_t *codes, uint8_t *norm_codes)
+{
+    const size_t d = ix->d, M = ix->code_size, dsub = d / M;
+    orc_hnsw *g = ix->quantizer;
+    const float *centroid = g->vectors + (size_t)centroid_idx * d;
+    /* :47-62 nearest first; the nearest one (the centroid itself) is dropped */
+    uint32_t *ids = (uint32_t *)malloc((nsubc + 1) * sizeof(uint32_t));
+    float *dists = (float *)malloc((nsubc + 1) * sizeof(float));
+    size_t r = orc_hnsw_search_knn(g, centroid, ix->efSearch, nsubc + 1, ids, dists);
+    if (r != nsubc + 1) {
+        free(ids);
+        free(dists);
+        return -1;
+    }
+    float *cv_norms = (float *)malloc(nsubc * sizeof(float));
+    for (size_t s = 0; s < nsubc; s++) {
+        nn_centroid_idxs[s] = ids[s + 1];
+        cv_norms[s] = dists[s + 1];
+    }
+    free(ids);
+    free(dists);
+    if (group_size == 0) { /* :63-64 */
+        free(cv_norms);
+        return 0;
+    }
+    float *cvs = (float *)malloc(2 * nsubc * d * sizeof(float)), *subc = cvs + nsubc * d;
+    for (size_t s = 0; s < nsubc; s++) { /* :70-74 fvec_madd(d, neighbour, -1, centroid, cv) */
+        const float *nb = g->vectors + (size_t)nn_centroid_idxs[s] * d;
+        for (size_t j = 0; j < d; j++)
+            cvs[s * d + j] = nb[j] + -1.0f * centroid[j];
+    }
+    *alpha = grouping_compute_alpha(d, nsubc, cvs, data, centroid, cv_norms, group_size); /* :77-79 */
+    for (size_t s = 0; s < nsubc; s++) /* :82-87 fvec_madd(d, centroid, alpha, cv, subcentroid) */
+        for (size_t j = 0; j < d; j++)
+            subc[s * d + j] = centroid[j] + *alpha * cvs[s * d + j];
+    float *res = (float *)malloc(3 * d * sizeof(float)), *tmp = res + d, *rec = res + 2 * d;
+    for (size_t i = 0; i < group_size; i++) {
+        const float *xi = data + i * d;
+        /* :673-689 first minimum of fvec_L2sqr(subcentroid, x) */
+        float min_dist = 0.0f;
+        long min_idx = -1;
+        for (size_t s = 0; s < nsubc; s++) {
+            float dist = orc_l2sqr(subc + s * d, xi, d);
+            if (min_idx == -1 || dist < min_dist) {
+                min_dist = dist;
+                min_idx = (long)s;
+            }
+        }
+        subcentroid_idxs[i] = (uint32_t)min_idx;
+        const float *sc = subc + (size_t)min_idx * d;
+        for (size_t j = 0; j < d; j++) /* :655-662 */
+            res[j] = xi[j] + -1.0f * sc[j];
+        const float *enc = res;
+        if (ix->do_opq) { /* :97-101 */
+            orc_opq_apply(ix->opq_A, res, d, tmp);
+            enc = tmp;
+        }
+        uint8_t *code = codes + i * M;
+        pq_compute_code(ix->pq_centroids, M, dsub, enc, code); /* :104-105 */
+        float *dec = ix->do_opq ? res : tmp;
+        for (size_t m = 0; m < M; m++) /* :108-109 */
+            memcpy(dec + m * dsub, ix->pq_centroids + (m * 256 + code[m]) * dsub, dsub * sizeof(float));
+        const float *back = dec;
+        if (ix->do_opq) { /* :112-116 */
+            for (size_t k = 0; k < d; k++) {
+                float acc = 0.0f;
+                for (size_t q = 0; q < d; q++)
+                    acc = fmaf(ix->opq_A[q * d + k], dec[q], acc);
+                tmp[k] = acc;
+            }
+            back = tmp;
+        }
+        for (size_t j = 0; j < d; j++) /* :664-671 */
+            rec[j] = back[j] + 1.0f * sc[j];
+        float norm = orc_inner_product_sse_order(rec, rec, d); /* :123-124 */
+        pq_compute_code(ix->norm_table, 1, 1, &norm, norm_codes + i); /* :127-128 */
+    }
+    free(res);
+    free(cvs);
+    free(cv_norms);
+    return 0;
+}
+
 /* =============================================================================================
  * .index files -- utils.h:53-81 (uint32 count + raw elements), IndexIVF_HNSW.cpp:637-663,758-779,
  * IndexIVF_HNSW_Grouping.cpp:397-483

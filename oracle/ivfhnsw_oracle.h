@@ -134,6 +134,20 @@ void orc_search_batch(const orc_index *ix, size_t nq, size_t k, const float *x, 
 void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const uint32_t *precomputed_idx,
                           uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes, float *out_norms);
 
+/* Grouping construction, IndexIVF_HNSW_Grouping.cpp:43-157 (add_group up to the distribution loops) for ONE
+ * group: neighbour centroids = searchKnn(centroid, nsubc+1) with ix->efSearch minus the nearest (:47-62),
+ * alpha (compute_alpha, :691-733), sub-centroids (:83-88), the sub-centroid of every point
+ * (compute_subcentroid_idxs, :673-689), then residual / [OPQ] / codes / decode / [OPQ back] / reconstruct /
+ * norm / norm code against the sub-centroids (:93-125).  Outputs: nn_centroid_idxs [nsubc], *alpha,
+ * subcentroid_idxs [group_size], codes [group_size*code_size], norm_codes [group_size].  The caller lays the
+ * list out sub-group by sub-group in arrival order (:127-155).  Returns 0, or -1 when the walk finds fewer than
+ * nsubc+1 centroids (the reference then leaves zero entries behind; defined here as an error).
+ * A neighbour at distance 0 (duplicate centroids) makes alpha candidates NaN; the reference's heap order with
+ * NaN keys is whatever std::priority_queue happens to do -- here a NaN candidate loses to every other one. */
+int orc_add_group_encode(const orc_index *ix, size_t nsubc, uint32_t centroid_idx, size_t group_size,
+                         const float *data, uint32_t *nn_centroid_idxs, float *alpha, uint32_t *subcentroid_idxs,
+                         uint8_t *codes, uint8_t *norm_codes);
+
 /* IndexIVF_HNSW.cpp:781-787 / Grouping.cpp:620-631. */
 void orc_compute_centroid_norms(const orc_hnsw *g, float *centroid_norms);
 void orc_compute_inter_centroid_dists(const orc_hnsw *g, size_t nsubc, const uint32_t *nn_idx, float *out);

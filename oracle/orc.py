@@ -79,6 +79,8 @@ def lib():
         L.orc_search_grouping_coarse.argtypes = [ip, sz, vp, vp, vp, vp, vp, sp]
         L.orc_search_batch.argtypes = [ip, sz, sz, vp, vp, vp, vp, vp, sp, C.c_int]
         L.orc_add_batch_encode.argtypes = [ip, sz, vp, vp, vp, vp, vp, vp]
+        L.orc_add_group_encode.argtypes = [ip, sz, C.c_uint32, sz, vp, vp, vp, vp, vp, vp]
+        L.orc_add_group_encode.restype = C.c_int
         L.orc_compute_centroid_norms.argtypes = [vp, vp]
         L.orc_compute_inter_centroid_dists.argtypes = [vp, sz, vp, vp]
         L.orc_rotate_quantizer.argtypes = [vp, vp]
@@ -269,6 +271,21 @@ class Index:
         norms = np.empty(n, np.float32)
         lib().orc_add_batch_encode(C.byref(self.ix), n, _p(x), _p(pidx), _p(idx), _p(codes), _p(ncodes), _p(norms))
         return idx, codes, ncodes, norms
+
+    def add_group_encode(self, nsubc, centroid_idx, data):
+        """IndexIVF_HNSW_Grouping.cpp:43-125 for one group: (nn_centroid_idxs, alpha, subcentroid_idxs, codes,
+        norm_codes).  efSearch of set_params drives searchKnn(centroid, nsubc + 1)."""
+        data = np.ascontiguousarray(data, np.float32).reshape(-1, self.d)
+        n = data.shape[0]
+        nn = np.empty(nsubc, np.uint32)
+        alpha = np.zeros(1, np.float32)
+        sub = np.empty(n, np.uint32)
+        codes = np.empty((n, self.ix.code_size), np.uint8)
+        ncodes = np.empty(n, np.uint8)
+        rc = lib().orc_add_group_encode(C.byref(self.ix), nsubc, int(centroid_idx), n, _p(data), _p(nn), _p(alpha),
+                                        _p(sub), _p(codes), _p(ncodes))
+        assert rc == 0, "the walk found fewer than nsubc + 1 centroids"
+        return nn, alpha[0], sub, codes, ncodes
 
     def search(self, x, k=1):
         """One query through the reference's single-query entry point."""

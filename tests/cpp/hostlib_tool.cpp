@@ -134,6 +134,49 @@ static int run(int argc, char **argv)
         delete index;
         return 0;
     }
+    if (cmd == "add_group" && argc == 16) {
+        // Grouping construction as the reference's driver does it (tests/test_ivfhnsw_grouping_sift1b.cpp:
+        // one add_group call per centroid with that centroid's points, then the two table passes and write)
+        const size_t d = atol(argv[2]), nc = atol(argv[3]), cs = atol(argv[4]), nsubc = atol(argv[5]);
+        const char *centroids = argv[6], *info = argv[7], *edges = argv[8], *ppq = argv[9], *pnorm = argv[10],
+                   *popq = argv[11], *pbase = argv[12], *pidx = argv[13], *pindex = argv[15];
+        const size_t n = atol(argv[14]);
+        IndexIVF_HNSW_Grouping *index = new IndexIVF_HNSW_Grouping(d, nc, cs, 8, nsubc);
+        index->build_quantizer(centroids, info, edges, 16, 500);
+        index->do_opq = strcmp(popq, "-") != 0;
+        delete index->pq;
+        index->pq = faiss::read_ProductQuantizer(ppq);
+        if (index->do_opq)
+            index->opq_matrix = dynamic_cast<faiss::LinearTransform *>(faiss::read_VectorTransform(popq));
+        delete index->norm_pq;
+        index->norm_pq = faiss::read_ProductQuantizer(pnorm);
+        index->quantizer->efSearch = 40;
+        std::vector<float> x(n * d);
+        {
+            std::ifstream in(pbase, std::ios::binary);
+            readXvec<float>(in, x.data(), d, n);
+        }
+        std::vector<uint32_t> pre(n);
+        {
+            std::ifstream in(pidx, std::ios::binary);
+            in.read((char *)pre.data(), n * sizeof(uint32_t));
+        }
+        for (size_t c = 0; c < nc; c++) {
+            std::vector<float> data;
+            std::vector<uint32_t> gids;
+            for (size_t i = 0; i < n; i++)
+                if (pre[i] == c) {
+                    data.insert(data.end(), x.begin() + i * d, x.begin() + (i + 1) * d);
+                    gids.push_back((uint32_t)(1000 + i));
+                }
+            index->add_group(c, gids.size(), data.data(), gids.data());
+        }
+        index->compute_centroid_norms();
+        index->compute_inter_centroid_dists();
+        index->write(pindex);
+        delete index;
+        return 0;
+    }
     if (cmd == "search" && argc == 22) {
         const bool grp = !strcmp(argv[2], "grouping");
         const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);

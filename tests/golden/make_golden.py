@@ -55,7 +55,49 @@ def run_encode_case(kw):
     return dict(idx=idx, codes=codes, norm_codes=ncodes, norms=norms, input_digest=digest), s
 
 
+GROUP_CASES = {
+    # Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-125): make_encode_case arguments + nsubc
+    "add_group_nsubc8_opq": (dict(seed=121, nc=120, d=64, M=8, opq=True, n=1500, hnsw_M=16), 8),
+}
+
+
+def group_inputs(kw, nsubc):
+    """Points of the case grouped by a seeded random centroid each (every fifth centroid stays empty)."""
+    s = synth.make_encode_case(**kw)
+    s["ox"].set_params(1, 0, 40)
+    rng = np.random.default_rng(kw["seed"] + 1)
+    nc, n = kw["nc"], kw["n"]
+    live = np.array([c for c in range(nc) if c % 5], np.uint32)
+    key = np.sort(live[rng.integers(0, len(live), size=n)])
+    x = (s["cents"][key] + rng.normal(0, 9.0, size=(n, kw["d"]))).astype(np.float32)
+    offsets = np.zeros(nc + 1, np.uint64)
+    offsets[1:] = np.cumsum(np.bincount(key, minlength=nc))
+    return s, x, offsets
+
+
+def run_group_case(kw, nsubc):
+    s, x, offsets = group_inputs(kw, nsubc)
+    nc = kw["nc"]
+    nn = np.zeros((nc, nsubc), np.uint32)
+    alphas = np.zeros(nc, np.float32)
+    sub = np.zeros(len(x), np.uint32)
+    codes = np.zeros((len(x), kw["M"]), np.uint8)
+    ncodes = np.zeros(len(x), np.uint8)
+    for c in range(nc):
+        a, b = int(offsets[c]), int(offsets[c + 1])
+        nn[c], al, sub[a:b], codes[a:b], ncodes[a:b] = s["ox"].add_group_encode(nsubc, c, x[a:b])
+        if b > a:
+            alphas[c] = al
+    digest = np.array([int(x.view(np.uint32).astype(np.uint64).sum()), int(s["graph"].links.astype(np.uint64).sum())],
+                      np.uint64)
+    return dict(nn=nn, alphas=alphas, sub=sub, codes=codes, norm_codes=ncodes, input_digest=digest), (s, x, offsets)
+
+
 if __name__ == "__main__":
+    for name, (kw, nsubc) in GROUP_CASES.items():
+        out, _ = run_group_case(kw, nsubc)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, out["alphas"][:6], out["sub"][:10])
     for name, kw in ENCODE_CASES.items():
         out, _ = run_encode_case(kw)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

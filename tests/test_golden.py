@@ -93,3 +93,33 @@ def test_device_reproduces_encode_golden(gpu, name):
     assert np.array_equal(idx, gold["idx"])
     assert np.array_equal(codes, gold["codes"])
     assert np.array_equal(ncodes, gold["norm_codes"])
+
+
+GROUP_NAMES = sorted(make_golden.GROUP_CASES)
+
+
+@pytest.mark.parametrize("name", GROUP_NAMES)
+def test_oracle_reproduces_add_group_golden(name):
+    out, _ = make_golden.run_group_case(*make_golden.GROUP_CASES[name])
+    g = _load(name)
+    assert np.array_equal(out["input_digest"], g["input_digest"]), "the case generator changed"
+    for key in ("nn", "sub", "codes", "norm_codes"):
+        assert np.array_equal(out[key], g[key]), key
+    assert np.array_equal(out["alphas"].view(np.uint32), g["alphas"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GROUP_NAMES)
+def test_device_reproduces_add_group_golden(gpu, name):
+    kw, nsubc = make_golden.GROUP_CASES[name]
+    s, x, offsets = make_golden.group_inputs(kw, nsubc)
+    g = gpu()
+    gr = s["graph"]
+    g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+    g.upload_codebooks(s["d"], s["M"], s["cb"], s["nt"], s["A"])
+    gold = _load(name)
+    nn, alphas, sub, codes, ncodes = g.encode_groups(nsubc, np.arange(kw["nc"], dtype=np.uint32), offsets, x, 40)
+    assert np.array_equal(nn, gold["nn"])
+    assert np.array_equal(alphas.view(np.uint32), gold["alphas"].view(np.uint32))
+    assert np.array_equal(sub, gold["sub"]) and np.array_equal(codes, gold["codes"])
+    assert np.array_equal(ncodes, gold["norm_codes"])

@@ -452,3 +452,44 @@ def test_add_batch_encode_matches_numpy_model(d, M, opq):
     idx2, codes2, ncodes2, _ = ox.add_batch_encode(x, pre)
     mc2, mn2, _ = np_add_batch_encode(x, pre, cents, cb, nt, A)
     assert np.array_equal(idx2, pre) and np.array_equal(codes2, mc2) and np.array_equal(ncodes2, mn2)
+
+
+def test_add_group_encode_matches_numpy_model():
+    """IndexIVF_HNSW_Grouping.cpp:43-125 for one group against an independent float32 evaluation: neighbours from
+    searchKnn(centroid, nsubc + 1) minus the nearest, alpha as the max-heap of (-dist, (numerator, denominator))
+    picks it, first nearest sub-centroid, then the add_batch chain against the sub-centroids."""
+    rng = np.random.default_rng(77)
+    d, M, nsubc, nc, n = 32, 4, 5, 60, 30
+    s = synth.make_encode_case(1, nc, d, M, True, n=8, hnsw_M=8)
+    ox, cents, cb, nt, A = s["ox"], s["cents"], s["cb"], s["nt"], s["A"]
+    ox.set_params(1, 0, 40)
+    c = 7
+    x = (cents[c] + rng.normal(0, 9, size=(n, d))).astype(F)
+    nn, alpha, sub, codes, ncodes = ox.add_group_encode(nsubc, c, x)
+    ids, dist = s["graph"].search_knn(cents[c], 40, nsubc + 1)
+    assert np.array_equal(nn, ids[1:])
+    cen = cents[c]
+    cv = np.stack([(cents[i] + (F(-1) * cen).astype(F)).astype(F) for i in nn])
+    num_s, den_s = F(0), F(0)
+    for p in x:
+        pv = (p + (F(-1) * cen).astype(F)).astype(F)
+        best = None
+        for k in range(nsubc):
+            num = np_ip_sse(cv[k], pv)
+            num = num if num > 0 else F(0)
+            den = dist[k + 1]
+            subc = (cen + (F(num / den) * cv[k]).astype(F)).astype(F)
+            cand = (-np_l2_ref(p, subc), num, den)
+            if best is None or best < cand:
+                best = cand
+        num_s, den_s = F(num_s + best[1]), F(den_s + best[2])
+    model_alpha = F(num_s / den_s)
+    assert np.float32(alpha).view(np.uint32) == model_alpha.view(np.uint32)
+    subcents = np.stack([(cen + (model_alpha * cv[k]).astype(F)).astype(F) for k in range(nsubc)])
+    msub = np.array([int(np.argmin([np_l2_ref(subcents[k], p) for k in range(nsubc)])) for p in x], np.uint32)
+    assert np.array_equal(sub, msub)
+    mc, mn, _ = np_add_batch_encode(x, msub, subcents, cb, nt, A)
+    assert np.array_equal(codes, mc) and np.array_equal(ncodes, mn)
+    # an empty group records the neighbours and nothing else
+    nn0, alpha0, sub0, codes0, nc0 = ox.add_group_encode(nsubc, c, np.zeros((0, d), F))
+    assert np.array_equal(nn0, nn) and alpha0 == 0 and len(sub0) == 0

@@ -58,5 +58,34 @@ def main():
                  args.n / t_pre / 1e6, x.nbytes / 1e6, (codes.nbytes + ncodes.nbytes + idx.nbytes) / 1e6), flush=True)
 
 
+def groups():
+    """IndexIVF_HNSW_Grouping::add_group for every centroid in one call: 2^20 points in 4096 groups, nsubc 64."""
+    import torch
+    import __graft_entry__ as ge
+    import synth
+    pkg = ge.load_pkg()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    nc, d, M, n, nsubc = 4096, 128, 16, 1 << 20, 64
+    tb = synth.make_throughput_tables(1234, nc, d, M, 1000 * nc)
+    counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
+    key = np.sort(rng.integers(0, nc, size=n)).astype(np.uint32)
+    x = (tb["centroids"][key] + rng.normal(0, 15.0, size=(n, d))).astype(np.float32)
+    offsets = np.zeros(nc + 1, np.uint64)
+    offsets[1:] = np.cumsum(np.bincount(key, minlength=nc))
+    g = pkg.GpuIndex(0)
+    g.upload_quantizer(counts, links, tb["centroids"], 0)
+    g.upload_codebooks(d, M, tb["pq_centroids"], tb["norm_table"])
+    g.encode_groups(nsubc, np.arange(64, dtype=np.uint32), offsets[:65], x[:int(offsets[64])], 220)  # warm-up
+    t0 = time.perf_counter()
+    g.encode_groups(nsubc, np.arange(nc, dtype=np.uint32), offsets, x, 220)
+    t = time.perf_counter() - t0
+    print("add_group: %d points in %d groups, nsubc %d: %.1f ms = %.2f M vectors/s" % (n, nc, nsubc, t * 1e3, n / t / 1e6),
+          flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "groups":
+        groups()
+        sys.exit(0)
     main()
