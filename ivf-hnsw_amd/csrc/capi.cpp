@@ -1035,10 +1035,13 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         if (k == 1 && nq < 1024)
             nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
         StageScope sc(h, IVFHNSW_STAGE_SCAN);
+        // a plan segment is a list (IVFADC) or a sub-group (Grouping): the mean length decides the scan form
+        const uint64_t nseg_all = (uint64_t)h->t.nc * (h->has_group ? (uint64_t)h->g.nsubc : 1);
+        const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
         HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                             h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
                             heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
-                            heap ? kHeapStreamCap : 0));
+                            heap ? kHeapStreamCap : 0, seg_hint));
     }
     // 6. select
     {

@@ -434,6 +434,98 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
     }
 }
 
+// The same scan for plans made of SHORT segments (Grouping: a sub-group holds ~12 codes at the reference's
+// nsubc 64): with positions dealt to lanes as above nearly every code starts in a new segment and pays a binary
+// search in the LDS plan.  Here a group of G lanes owns a whole segment (lane i its codes i, i+G, ...), groups take
+// segments round-robin, two segments per step so that two loads per lane are in flight: one plan read per
+// segment instead of a search per code.  Same keys, so same winner.
+template <int CS, int G>
+__global__ __launch_bounds__(256) void scan_k1_short_kernel(const uint8_t *__restrict__ codes,
+                                                            const uint8_t *__restrict__ norm_codes,
+                                                            const float *__restrict__ luts,
+                                                            const float *__restrict__ norm_table,
+                                                            const Seg *__restrict__ segs,
+                                                            const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
+                                                            unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
+    __shared__ float s_norm[256];
+    __shared__ unsigned long long s_red[4];
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x / nsplit;
+    const int split = blockIdx.x - q * nsplit;
+    const PlanHdr h = hdr[q];
+    if (h.total == 0)
+        return;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
+        float4 *dst = reinterpret_cast<float4 *>(s_lut);
+        for (int i = tid; i < CS * 64; i += 256)
+            dst[i] = src[i];
+        s_norm[tid] = norm_table[tid];
+    }
+    __syncthreads();
+    constexpr int NG = 256 / G; // groups per block
+    const int gid = tid / G, li = tid % G;
+    const Seg *sq = segs + (size_t)q * max_seg;
+    unsigned long long best = kKeyInit;
+    const uint32_t stride = (uint32_t)NG * nsplit;
+    for (uint32_t s0 = (uint32_t)split * NG + gid; s0 < h.nseg; s0 += 2 * stride) {
+        const uint32_t s1 = s0 + stride;
+        const Seg a = sq[s0];
+        Seg b;
+        b.start = 0, b.len = 0, b.vpos = 0, b.cterm = 0.f;
+        if (s1 < h.nseg)
+            b = sq[s1];
+        const uint32_t n = a.len > b.len ? a.len : b.len;
+        for (uint32_t off = li; off < n; off += G) {
+            uint32_t wa[CS / 4], wb[CS / 4];
+            uint32_t na = 0, nb = 0;
+            const bool oa = off < a.len, ob = off < b.len;
+            if (oa) {
+                load_code_words<CS>(codes, a.start + off, wa);
+                na = norm_codes[a.start + off];
+            }
+            if (ob) {
+                load_code_words<CS>(codes, b.start + off, wb);
+                nb = norm_codes[b.start + off];
+            }
+            if (oa) {
+                const float sum = adc_sum<CS>(s_lut, wa);
+                const float dist = __fsub_rn(__fadd_rn(a.cterm, s_norm[na]), __fmul_rn(2.0f, sum));
+                if (dist < FLT_MAX) {
+                    const unsigned long long key =
+                        ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (a.vpos + off);
+                    best = key < best ? key : best;
+                }
+            }
+            if (ob) {
+                const float sum = adc_sum<CS>(s_lut, wb);
+                const float dist = __fsub_rn(__fadd_rn(b.cterm, s_norm[nb]), __fmul_rn(2.0f, sum));
+                if (dist < FLT_MAX) {
+                    const unsigned long long key =
+                        ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (b.vpos + off);
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    }
+    best = wave_min_u64(best);
+    if ((tid & 63) == 0)
+        s_red[tid >> 6] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = s_red[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+            m = s_red[i] < m ? s_red[i] : m;
+        if (nsplit == 1)
+            keys[q] = m;
+        else if (m < kKeyInit)
+            atomicMin(&keys[q], m);
+    }
+}
+
 // tuning knob for A/B runs on the device: IVFHNSW_SCAN_REP = 1, 2 or 4 (LDS copies of the table)
 static int scan_rep_choice()
 {
@@ -448,10 +540,30 @@ static int scan_rep_choice()
 template <int CS>
 static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
                                  const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
-                                 uint64_t *keys)
+                                 uint64_t *keys, int seg_len_hint)
 {
     dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
+    // short segments (Grouping sub-groups): a lane group per segment; IVFHNSW_SCAN_SHORT=0 keeps the position form
+    static const bool allow_short = [] {
+        const char *e = getenv("IVFHNSW_SCAN_SHORT");
+        return !(e && atoi(e) == 0);
+    }();
+    if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
+#define IVFHNSW_SCAN_SHORT(GG)                                                                                        \
+    hipLaunchKernelGGL((scan_k1_short_kernel<CS, GG>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table, \
+                       segs, hdr, max_seg, nsplit, k64)
+        if (seg_len_hint <= 8)
+            IVFHNSW_SCAN_SHORT(8);
+        else if (seg_len_hint <= 16)
+            IVFHNSW_SCAN_SHORT(16);
+        else if (seg_len_hint <= 32)
+            IVFHNSW_SCAN_SHORT(32);
+        else
+            IVFHNSW_SCAN_SHORT(64);
+#undef IVFHNSW_SCAN_SHORT
+        return hipGetLastError();
+    }
 #define IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, UU)                                                                     \
     hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, UU, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
                        luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64)
@@ -491,17 +603,17 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
 
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys, uint64_t *stream,
-                       uint32_t *stream_len, uint32_t stream_cap)
+                       uint32_t *stream_len, uint32_t stream_cap, int seg_len_hint)
 {
     if (nq == 0)
         return hipSuccess;
     if (k != 1)
         return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys, stream, stream_len, stream_cap);
     switch (t.M) {
-    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
-    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
-    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
-    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys);
+    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
     default: return hipErrorInvalidValue;
     }
 }

@@ -56,10 +56,11 @@ def merge_keys_labels(keys, labels_of_owner, group=None):
 
 
 def _all_gather_rows(buf, rank, per, group):
-    """In-place all-gather of `per` rows per rank into buf (RCCL: ncclAllGather in place)."""
+    """All-gather of `per` rows per rank into buf (RCCL: ncclAllGather).  The rank's own rows are sent from a
+    copy: whether an input that aliases the output is accepted is the backend's business, and the copy is 1.3 MB."""
     import torch.distributed as dist
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(buf, buf[rank * per:(rank + 1) * per], group=group)
+        dist.all_gather_into_tensor(buf, buf[rank * per:(rank + 1) * per].clone(), group=group)
     else:  # gloo (CPU tests / single-GPU rehearsal): stage through the host
         host = buf.cpu()
         parts = [host[r * per:(r + 1) * per].clone() for r in range(dist.get_world_size(group))]
