@@ -582,6 +582,13 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     h->gr.counts = h->q_counts.as<uint8_t>();
     h->gr.links = h->q_links.as<uint32_t>();
     h->gr.vectors = h->q_vectors.as<float>();
+    {
+        static const int merge = [] {
+            const char *e = getenv("IVFHNSW_WALK_MERGE");
+            return (e && atoi(e) == 0) ? 0 : 1;
+        }();
+        h->gr.merge_admissions = merge;
+    }
     h->gr.qrows = nullptr;
     h->gr.nbrows = nullptr;
     h->gr.nb_rows = 0;

@@ -71,6 +71,7 @@ struct GraphTables {
     // nb_rows*128-byte read per expansion, issued together with the link list.  NULL = gather from qrows.
     const uint8_t *nbrows;
     int nb_rows;
+    int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
 };
 
 // y[q][i] = fmaf chain over k of A[i][k] * x[q][k]  (IndexIVF_HNSW.cpp:240)

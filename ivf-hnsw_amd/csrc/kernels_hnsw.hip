@@ -168,8 +168,8 @@ template <int NCH> struct RSet {
 // (19.6 M scattered atomics per 10 k queries, ~1 ms; MI355X guide: scattered atomics run ~17x below the
 // coalesced rate).
 // The bucket count follows the occupancy the kernel is built for (MINW waves per SIMD, 4 * MINW per CU sharing
-// 160 KB of LDS): 8 KB of buckets at 4, 6 KB at 5, 5 KB at 6, 3 KB at 8.
-constexpr int vis_buckets(int minw) { return minw <= 4 ? 1024 : minw == 5 ? 768 : minw <= 7 ? 640 : 384; }
+// 160 KB of LDS): 7 KB of buckets at 4 (with the merge buffer below that is 10 KB per wave), 6 KB at 5, 5 KB at 6.
+constexpr int vis_buckets(int minw) { return minw <= 4 ? 896 : minw == 5 ? 768 : minw <= 7 ? 640 : 384; }
 
 // TAGW = bits per tag: 8 (8 tags per bucket, graphs up to 255 * 1024 nodes), 12 (5 per bucket, up to 4095 * 1024),
 // 16 (4 per bucket, up to 65535 * 1024); 0 = no LDS set, global bitmap only.  Fields are scanned SWAR-style:
@@ -280,10 +280,13 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem + (size_t)(g.d + dp) * sizeof(float) + 512);
     constexpr int NB = vis_buckets(MINW);
     unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0}, st_t = 0;
-    unsigned long long *vt = tail + kTailCap; // [NB] when TAGW != 0
+    // the tail doubles as the merge buffer of a pass's admissions (ef + 8 entries; only used while the tail is empty)
+    const int merge_extra = (NCH <= 2 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0;
+    unsigned long long *vt = tail + kTailCap + merge_extra; // [NB] when TAGW != 0
     constexpr bool LDSVIS = TAGW != 0;
 
     const int lane = threadIdx.x;
+    const bool merge_on = g.merge_admissions != 0;
     constexpr bool prefilter = FMODE != 0;
     constexpr bool inline_rows = FMODE == 2;
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
@@ -622,6 +625,56 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     st_acc[6] += (unsigned long long)__popcll(__ballot(active && (lane & 7) == 0));
                     st_acc[7] += (unsigned long long)__popcll(cand);
                 }
+                if (NCH <= 2 && merge_on && n == ef && ntail == 0 && cand) {
+                    // ---- all admissions of the pass in one step.  With the set full, inserting the pass's
+                    // candidates one by one in link order (below) leaves the ef smallest keys of set + candidates,
+                    // PROVIDED the ef-th and (ef+1)-th of the merged order differ in distance: then every loser has
+                    // a distance above the final maximum, so no strict-'<' tie decided anything and nothing can
+                    // wait in the tail.  So: rank every candidate among the set and among the candidates, every
+                    // set entry among the candidates, scatter through LDS, look at the boundary; a tie there
+                    // leaves the registers untouched and takes the sequential path.
+                    const bool is_cand = (cand >> lane) & 1ull;
+                    const unsigned long long Kc = mk_key(dq, nbq);
+                    int up[NCH]; // candidates below this lane's set entries
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++)
+                        up[cc] = 0;
+                    int cand_below = 0, set_below = 0;
+                    for (unsigned long long cm = cand; cm; cm &= cm - 1) {
+                        const int b = __ffsll((long long)cm) - 1;
+                        const unsigned long long Kj =
+                            mk_key(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b)),
+                                   (uint32_t)__builtin_amdgcn_readlane((int)nbq, b));
+                        int below = 0;
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) {
+                            const bool lt = cc * 64 + lane < ef && (R.r[cc] & ~1ull) < Kj;
+                            below += __popcll(__ballot(lt));
+                            up[cc] += lt ? 0 : 1;
+                        }
+                        cand_below += Kj < Kc ? 1 : 0;
+                        set_below = lane == b ? below : set_below;
+                    }
+                    unsigned long long *mb = tail;
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++)
+                        if (cc * 64 + lane < ef)
+                            mb[cc * 64 + lane + up[cc]] = R.r[cc];
+                    if (is_cand)
+                        mb[set_below + cand_below] = Kc;
+                    __syncthreads();
+                    const bool clean = key_dist_bits(mb[ef - 1]) != key_dist_bits(mb[ef]);
+                    if (clean) {
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++)
+                            if (cc * 64 + lane < ef)
+                                R.r[cc] = mb[cc * 64 + lane];
+                        if (STAMPS)
+                            st_acc[8] += (unsigned long long)__popcll(__ballot(is_cand && set_below + cand_below < ef));
+                        cand = 0;
+                    }
+                    __syncthreads();
+                }
                 while (cand) { // hnswalg.cpp:93-103, in link order
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1;
@@ -750,7 +803,8 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
         return e ? (size_t)atoi(e) : (size_t)0;
     }();
     const size_t shm = (size_t)(g.d + ((g.qrows && !g.nbrows) ? g.d : 0)) * sizeof(float) + 512 +
-                       (size_t)kTailCap * sizeof(unsigned long long) +
+                       (size_t)(kTailCap + ((ef <= 128 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) *
+                           sizeof(unsigned long long) +
                        (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
     const int fmode = g.nbrows ? 2 : g.qrows ? 1 : 0;
 #define IVFHNSW_WALK_F(N, W, T, F)                                                                                    \

@@ -589,6 +589,10 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
             IVFHNSW_SCAN(64, 2, 256);
         else
             IVFHNSW_SCAN(64, 1, 256);
+    } else if (max_seg <= 256) {
+        // nprobe 65..256 (the DEEP1B preset probes 128 lists): a 5 KB plan instead of 20 KB keeps 7 workgroups
+        // per CU resident instead of 4
+        IVFHNSW_SCAN(256, 1, 256);
     } else {
         IVFHNSW_SCAN(1024, 1, 256);
     }
