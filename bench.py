@@ -183,6 +183,15 @@ def main():
     stage = g.stage_ms()
     g.set_profiling(False)
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
+    # the host-pointer entry point of the C ABI (queries in, distances and labels out over PCIe): never `value`,
+    # reported beside it
+    host_qps = None
+    if world == 1:
+        g.search(queries[:nq], 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        t_h = time.perf_counter()
+        for _ in range(3):
+            g.search(queries[:nq], 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        host_qps = 3 * nq / (time.perf_counter() - t_h)
 
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
@@ -242,6 +251,7 @@ def main():
                 "bytes_per_code": bytes_per_code, "codes_per_launch": ncodes, "avg_launch_ms": round(scan_avg_ms, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
+            "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
         }
 
         if world == 1 and scale == 1 and not args.no_cpu_baseline:
