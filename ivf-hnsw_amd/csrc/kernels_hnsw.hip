@@ -67,6 +67,16 @@ template <int NCH> struct RSet {
     __device__ __forceinline__ unsigned long long get(int idx) const // idx wave-uniform
     {
         const int c = idx >> 6, l = __builtin_amdgcn_readfirstlane(idx & 63);
+        if constexpr (NCH <= 2) {
+            // both registers read, one kept: four readlanes and two scalar selects, no branch
+            unsigned long long v = readlane_u64(r[0], l);
+#pragma unroll
+            for (int cc = 1; cc < NCH; cc++) {
+                const unsigned long long t = readlane_u64(r[cc], l);
+                v = c == cc ? t : v;
+            }
+            return v;
+        }
         unsigned long long v = 0;
 #pragma unroll
         for (int cc = 0; cc < NCH; cc++)
@@ -428,15 +438,21 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         for (;;) {
             // ---- candidateSet.top(): first unexpanded entry of R, ties -> largest id; tail joins at dist == max
             const int first = R.first_unexpanded(n, lane);
-            const uint32_t maxbits = key_dist_bits(R.get(n - 1));
             int pick = -1;      // index in R, or
             int pick_tail = -1; // index in tail
             uint32_t pick_id = 0;
             if (first >= 0) {
-                const uint32_t db = key_dist_bits(R.get(first));
-                pick = R.last_unexpanded_with(db, first, n, lane);
-                pick_id = key_id(R.get(pick));
-                if (db == maxbits && ntail > 0) {
+                const unsigned long long kfirst = R.get(first);
+                const uint32_t db = key_dist_bits(kfirst);
+                // equal distances sit next to each other: only if the following entry shares this one's distance
+                // can a larger id with the same distance exist (the full search is the rare path)
+                pick = first;
+                pick_id = key_id(kfirst);
+                if (first + 1 < n && key_dist_bits(R.get(first + 1)) == db) {
+                    pick = R.last_unexpanded_with(db, first, n, lane);
+                    pick_id = key_id(R.get(pick));
+                }
+                if (ntail > 0 && db == key_dist_bits(R.get(n - 1))) {
                     // tail entries share this distance; the larger id pops first
                     for (int t = 0; t < ntail; t++)
                         if (key_id(tail[t]) > pick_id) {
