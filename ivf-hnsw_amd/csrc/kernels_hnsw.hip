@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         int q16_w = 0; // 128 * ||Q / 256||^2 of the two-byte query Q below (floor)
         int x_const = 0;    // 255 * sum XH
         bool x_any = false; // some component of this query lies outside the byte range
+        bool x_hi = false;  // ... above it (the XH plane is not all zero)
         if (prefilter) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 // 128 * sum Q^2 / 65536 = 128 hh + hl + ll / 512  (< 2^31; the floor only lowers the bound)
                 q16_w = 128 * s_hh + s_hl + (s_ll >> 9);
                 x_any = (s_xl | s_xh) != 0;
+                x_hi = s_xh != 0;
                 x_const = 255 * s_xh;
                 pf_slack_q = 1.001f * sqrtf(dq_sq);
                 pf_bonus = 0.999f * bonus;
@@ -543,7 +545,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
                                 xlr = __builtin_amdgcn_udot4(xl[c], ws[c], xlr, false);
-                                xhr = __builtin_amdgcn_udot4(xh[c], ws[c], xhr, false);
+                                if (x_hi) // wave-uniform; SIFT-like queries only ever leave the range downwards
+                                    xhr = __builtin_amdgcn_udot4(xh[c], ws[c], xhr, false);
                             }
                             X[i] = oct_sum((int)(xlr - xhr));
                         }
