@@ -67,7 +67,7 @@ template <int NCH> struct RSet {
     __device__ __forceinline__ unsigned long long get(int idx) const // idx wave-uniform
     {
         const int c = idx >> 6, l = __builtin_amdgcn_readfirstlane(idx & 63);
-        if constexpr (NCH <= 2) {
+        if constexpr (NCH <= 4) {
             // both registers read, one kept: four readlanes and two scalar selects, no branch
             unsigned long long v = readlane_u64(r[0], l);
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     constexpr int NB = vis_buckets(MINW);
     unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     // the tail doubles as the merge buffer of a pass's admissions (ef + 8 entries; only used while the tail is empty)
-    const int merge_extra = (NCH <= 2 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0;
+    const int merge_extra = (NCH <= 4 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0;
     unsigned long long *vt = tail + kTailCap + merge_extra; // [NB] when TAGW != 0
     constexpr bool LDSVIS = TAGW != 0;
 
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     st_acc[6] += (unsigned long long)__popcll(__ballot(active && (lane & 7) == 0));
                     st_acc[7] += (unsigned long long)__popcll(cand);
                 }
-                if (NCH <= 2 && merge_on && n == ef && ntail == 0 && cand) {
+                if (NCH <= 4 && merge_on && n == ef && ntail == 0 && cand) {
                     // ---- all admissions of the pass in one step.  With the set full, inserting the pass's
                     // candidates one by one in link order (below) leaves the ef smallest keys of set + candidates,
                     // PROVIDED the ef-th and (ef+1)-th of the merged order differ in distance: then every loser has
@@ -822,7 +822,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
         return e ? (size_t)atoi(e) : (size_t)0;
     }();
     const size_t shm = (size_t)(g.d + ((g.qrows && !g.nbrows) ? g.d : 0)) * sizeof(float) + 512 +
-                       (size_t)(kTailCap + ((ef <= 128 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) *
+                       (size_t)(kTailCap + ((ef <= 256 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) *
                            sizeof(unsigned long long) +
                        (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
     const int fmode = g.nbrows ? 2 : g.qrows ? 1 : 0;
