@@ -160,6 +160,7 @@ hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float 
     size_t shm = (size_t)LUT_QB * t.d * sizeof(float);
     switch (t.dsub) {
     case 4: hipLaunchKernelGGL(lut_kernel<4>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    case 6: hipLaunchKernelGGL(lut_kernel<6>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
     case 8: hipLaunchKernelGGL(lut_kernel<8>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
     case 12: hipLaunchKernelGGL(lut_kernel<12>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
     case 16: hipLaunchKernelGGL(lut_kernel<16>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
@@ -174,48 +175,76 @@ hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float 
 // ---------------------------------------------------------------------------------------------
 // IVF scan plan (IndexIVF_HNSW.cpp:267-292): probes nearest first, empty lists skipped, stop after
 // the list that makes ncode >= max_codes.  Depends only on coarse results and list sizes, never on
-// codes, so it is computed up front and the scan itself is order-free.  One thread per query.
+// codes, so it is computed up front and the scan itself is order-free.
 // ---------------------------------------------------------------------------------------------
-__global__ void plan_ivf_kernel(IvfTables t, const uint32_t *__restrict__ cid, const float *__restrict__ cd, int nq,
-                                int nprobe, unsigned long long max_codes, Seg *__restrict__ segs,
-                                uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr, int max_seg,
-                                unsigned long long *__restrict__ keys, int k)
+__device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long long v, int lane)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v += o;
+    }
+    return v;
+}
+
+// One wavefront per query, lanes over the probes (chunks of 64): list sizes in parallel, the max_codes prefix
+// rule by a wave scan -- list i is scored iff fewer than max_codes codes precede it in probe order.
+__global__ __launch_bounds__(256) void plan_ivf_kernel(IvfTables t, const uint32_t *__restrict__ cid,
+                                                       const float *__restrict__ cd, int nq, int nprobe,
+                                                       unsigned long long max_codes, Seg *__restrict__ segs,
+                                                       uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr,
+                                                       int max_seg, unsigned long long *__restrict__ keys, int k)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (q >= nq)
         return;
-    for (int j = 0; j < k; j++)
+    for (int j = lane; j < k; j += 64)
         keys[(size_t)q * k + j] = kKeyInit;
-    unsigned long long ncode = 0;
+    unsigned long long ncode = 0; // codes of the lists visited so far (wave-uniform)
     uint32_t nl = 0, ns = 0;
     Seg *sq = segs + (size_t)q * max_seg;
     uint32_t *lq = lpos + (size_t)q * max_seg;
-    for (int i = 0; i < nprobe; i++) {
-        const uint32_t c = cid[(size_t)q * nprobe + i];
-        if (c >= t.nc)
-            continue; // padding slot (fewer than nprobe coarse results)
-        const unsigned long long n = t.goff[c + 1] - t.goff[c];
-        if (n == 0)
-            continue;
-        if (c % t.shard_world == t.shard_rank) {
+    for (int base = 0; base < nprobe && (ncode < max_codes || ncode == 0); base += 64) {
+        const int i = base + lane;
+        uint32_t c = 0xffffffffu;
+        if (i < nprobe)
+            c = cid[(size_t)q * nprobe + i];
+        const bool ok = c < t.nc; // padding slots (fewer than nprobe coarse results) hold 0xffffffff
+        unsigned long long n = 0;
+        if (ok)
+            n = t.goff[c + 1] - t.goff[c];
+        const unsigned long long incl = wave_incl_scan_u64(n, lane) + ncode;
+        const unsigned long long excl = incl - n;
+        // the check follows the scoring (IndexIVF_HNSW.cpp:290-292): the first non-empty list is always scored
+        const bool take = n != 0 && (excl < max_codes || excl == 0);
+        const bool owned = take && (c % t.shard_world == t.shard_rank);
+        const unsigned long long om = __ballot(owned);
+        const unsigned long long own_incl = wave_incl_scan_u64(owned ? n : 0ull, lane);
+        if (owned) {
+            const uint32_t r = ns + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
             Seg sg;
             sg.start = t.loff[c];
             sg.len = (uint32_t)n;
-            sg.vpos = (uint32_t)ncode;
+            sg.vpos = (uint32_t)excl;
             sg.cterm = __fsub_rn(cd[(size_t)q * nprobe + i], t.centroid_norms[c]);
-            sq[ns] = sg;
-            lq[ns] = nl;
-            nl += (uint32_t)n;
-            ns++;
+            sq[r] = sg;
+            lq[r] = nl + (uint32_t)(own_incl - n);
         }
-        ncode += n;
-        if (ncode >= max_codes)
-            break;
+        ns += (uint32_t)__popcll(om);
+        nl += (uint32_t)__shfl(own_incl, 63, 64);
+        // codes visited: everything up to and including the list that reached max_codes
+        const unsigned long long stop = __ballot(take && incl >= max_codes);
+        const int last = stop ? __ffsll((long long)stop) - 1 : 63;
+        ncode = __shfl(incl, last, 64);
     }
-    PlanHdr h;
-    h.nseg = ns;
-    h.total = nl;
-    hdr[q] = h;
+    if (lane == 0) {
+        PlanHdr h;
+        h.nseg = ns;
+        h.total = nl;
+        hdr[q] = h;
+    }
 }
 
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids, const float *coarse_dists,
@@ -224,7 +253,7 @@ hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *co
 {
     if (nq == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(plan_ivf_kernel, dim3((nq + 127) / 128), dim3(128), 0, s, t, coarse_ids, coarse_dists, nq,
+    hipLaunchKernelGGL(plan_ivf_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, t, coarse_ids, coarse_dists, nq,
                        nprobe, (unsigned long long)max_codes, segs, lpos, hdr, max_seg,
                        reinterpret_cast<unsigned long long *>(keys), k);
     return hipGetLastError();
