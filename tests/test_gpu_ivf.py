@@ -29,6 +29,11 @@ def _same(dist, lab, ref_d, ref_l):
     (dict(seed=13, nc=128, d=96, M=16, n_base=10000, nq=64), 32, 5000, 64),        # DEEP shape: dsub = 6
     (dict(seed=14, nc=128, d=128, M=32, n_base=8000, nq=32), 4, 1000, 20),         # PQ32
     (dict(seed=15, nc=64, d=64, M=4, n_base=4000, nq=32, efConstruction=60), 64, 10 ** 9, 64),  # every list probed
+    # the limit is checked AFTER a list is scored (IndexIVF_HNSW.cpp:290-292): max_codes 0 and 1 still score
+    # the first non-empty list, empty lists in front of it are passed over
+    (dict(seed=16, nc=128, d=64, M=8, n_base=1500, nq=48, efConstruction=60, empty_frac=0.5), 16, 0, 32),
+    (dict(seed=16, nc=128, d=64, M=8, n_base=1500, nq=48, efConstruction=60, empty_frac=0.5), 16, 1, 32),
+    (dict(seed=17, nc=512, d=64, M=8, n_base=20000, nq=48, efConstruction=60, empty_frac=0.3), 200, 2500, 210),  # > 64 probes: chunks
 ])
 def test_ivf_top1_matches_oracle(gpu, kw, nprobe, max_codes, ef):
     c = corpus(**kw)
