@@ -20,13 +20,14 @@ namespace ivfhnsw_gpu_impl {
 constexpr int TK_N = 2048;      // sort buffer entries (top | candidates)
 constexpr int TK_KCAP = 1024;   // max k
 constexpr int TK_SEGCAP = 512;
-constexpr int TK_U = 2;
+constexpr int TK_U = 4;
 
-__device__ __forceinline__ void bitonic_sort_2048(unsigned long long *buf, int tid)
+// ascending bitonic sort of buf[0 .. n), n a power of two <= TK_N (entries beyond the live ones hold ~0)
+__device__ __forceinline__ void bitonic_sort_n(unsigned long long *buf, int n, int tid)
 {
-    for (int size = 2; size <= TK_N; size <<= 1) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < TK_N / 2; i += 256) {
+            for (int i = tid; i < n / 2; i += 256) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -57,10 +58,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
     __shared__ __attribute__((aligned(16))) Seg s_seg[TK_SEGCAP];
     __shared__ uint32_t s_lpos[TK_SEGCAP + 1];
     __shared__ unsigned long long s_buf[TK_N];
-    __shared__ uint32_t s_ncand;
     __shared__ unsigned long long s_T;
-    __shared__ uint32_t s_wcnt[TK_U][4]; // candidates per (unroll step, wave) of the current iteration
-    __shared__ uint32_t s_slen;          // length of this query's candidate stream so far
+    __shared__ uint32_t s_wcnt[2][TK_U][4]; // candidates per (unroll step, wave), double buffered by iteration
 
     const int tid = threadIdx.x;
     const int q = blockIdx.x;
@@ -79,28 +78,36 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
         s_norm[tid] = norm_table[tid];
         for (int i = tid; i < TK_N; i += 256)
             s_buf[i] = ~0ull;
-        if (tid == 0) {
-            s_ncand = 0;
-            s_slen = 0;
+        if (tid == 0)
             s_T = kKeyInit;
-        }
     }
+    // fill level of the sort buffer and length of the candidate stream: every thread keeps the same copy (they
+    // all add the same per-wave counts), so neither needs a broadcast
+    uint32_t ncand = 0, slen = 0;
+    unsigned long long T = kKeyInit;
+    uint32_t iter = 0;
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t *lq = lpos + (size_t)q * max_seg;
 
     auto flush = [&]() {
-        // all candidates are in s_buf[TK_KCAP .. TK_KCAP + ncand); sort everything, keep the k smallest
+        // all candidates are in s_buf[k .. k + ncand); sort everything, keep the k smallest
         __syncthreads();
-        bitonic_sort_2048(s_buf, tid);
-        for (int i = tid; i < TK_N; i += 256)
+        // only the live prefix is sorted: the first flush holds a whole iteration of candidates, later ones a few
+        // dozen -- the 2048-entry sort was three quarters of this kernel's instructions
+        int n_sort = 64;
+        while (n_sort < k + (int)ncand)
+            n_sort <<= 1;
+        bitonic_sort_n(s_buf, n_sort, tid);
+        for (int i = tid; i < n_sort; i += 256)
             if (i >= k)
                 s_buf[i] = ~0ull;
         if (tid == 0) {
-            s_ncand = 0;
             const unsigned long long kth = s_buf[k - 1];
             s_T = kth < kKeyInit ? kth : kKeyInit;
         }
         __syncthreads();
+        ncand = 0;
+        T = s_T;
     };
 
     for (uint32_t cs = 0; cs < h.nseg; cs += TK_SEGCAP) {
@@ -115,90 +122,100 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
             s_lpos[cn] = ch;
         __syncthreads();
         const uint32_t cl = s_lpos[0];
-        uint32_t s = 0;
-        for (uint32_t base = cl; base < ch; base += 256 * TK_U) {
-            // read the fill level before anyone can add to it again, so the decision is uniform
-            const uint32_t fill = s_ncand;
-            __syncthreads();
-            if (fill > TK_N - TK_KCAP - 256 * TK_U)
+        // the segment this lane is inside, kept in registers (positions only grow)
+        uint32_t s = 0, seg_lo = 0, seg_hi = 0, seg_start = 0, seg_vpos = 0;
+        float seg_ct = 0.f;
+        for (uint32_t base = cl; base < ch; iter++) {
+            // no threshold yet (every code passes): take a quarter iteration and sort 512 entries instead of 2048
+            if ((ncand && T == kKeyInit) || ncand + k + 256 * TK_U > TK_N)
                 flush();
-            const unsigned long long T = s_T;
+            const int u_now = T == kKeyInit ? 1 : TK_U;
             unsigned long long key[TK_U];
             bool pass[TK_U];
+            uint32_t w[TK_U][CS / 4], nbv[TK_U], vp[TK_U];
+            float ct[TK_U];
+            bool ok[TK_U];
 #pragma unroll
             for (int u = 0; u < TK_U; u++) {
                 const uint32_t p = base + u * 256 + tid;
+                ok[u] = u < u_now && p < ch;
+                if (ok[u]) {
+                    if (p >= seg_hi) {
+                        uint32_t a = s, b = cn - 1;
+                        while (a < b) {
+                            const uint32_t mid = (a + b) >> 1;
+                            if (s_lpos[mid + 1] > p)
+                                b = mid;
+                            else
+                                a = mid + 1;
+                        }
+                        s = a;
+                        const Seg sg = s_seg[s];
+                        seg_lo = s_lpos[s];
+                        seg_hi = seg_lo + sg.len;
+                        seg_start = sg.start;
+                        seg_vpos = sg.vpos;
+                        seg_ct = sg.cterm;
+                    }
+                    const uint32_t off = p - seg_lo;
+                    const uint32_t gi = seg_start + off;
+                    load_code_words<CS>(codes, gi, w[u]);
+                    nbv[u] = norm_codes[gi];
+                    vp[u] = seg_vpos + off;
+                    ct[u] = seg_ct;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TK_U; u++) {
                 pass[u] = false;
                 key[u] = 0;
-                if (p < ch) {
-                    uint32_t a = s, b = cn - 1;
-                    while (a < b) {
-                        const uint32_t mid = (a + b) >> 1;
-                        if (s_lpos[mid + 1] > p)
-                            b = mid;
-                        else
-                            a = mid + 1;
-                    }
-                    s = a;
-                    const Seg sg = s_seg[s];
-                    const uint32_t off = p - s_lpos[s];
-                    const uint32_t gi = sg.start + off;
-                    uint32_t w[CS / 4];
-                    load_code_words<CS>(codes, gi, w);
-                    const uint32_t nb = norm_codes[gi];
-                    const float sum = adc_sum<CS>(s_lut, w);
-                    const float tt = __fadd_rn(sg.cterm, s_norm[nb]);
+                if (ok[u]) {
+                    const float sum = adc_sum<CS>(s_lut, w[u]);
+                    const float tt = __fadd_rn(ct[u], s_norm[nbv[u]]);
                     const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
                     if (dist < FLT_MAX) {
-                        key[u] = ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (sg.vpos + off);
+                        key[u] = ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | vp[u];
                         pass[u] = key[u] < T;
                     }
                 }
             }
             // Append the candidates IN SCAN ORDER (position = unroll step, then wave, then lane): the buffer is
-            // then a stream a sequential consumer can replay (heap-order output, below).
+            // then a stream a sequential consumer can replay (heap-order output, below).  One barrier per
+            // iteration: the per-wave counts are double buffered, the running totals live in registers.
             unsigned long long bal[TK_U];
+            uint32_t(*wc)[4] = s_wcnt[iter & 1];
 #pragma unroll
             for (int u = 0; u < TK_U; u++) {
                 bal[u] = __ballot(pass[u]);
                 if ((tid & 63) == 0)
-                    s_wcnt[u][tid >> 6] = (uint32_t)__popcll(bal[u]);
+                    wc[u][tid >> 6] = (uint32_t)__popcll(bal[u]);
             }
             __syncthreads();
-            {
-                uint32_t before = 0, total = 0;
+            uint32_t total = 0, mine[TK_U];
+#pragma unroll
+            for (int u = 0; u < TK_U; u++) {
+                mine[u] = total; // candidates of earlier unroll steps and earlier waves of this step
+#pragma unroll
+                for (int w2 = 0; w2 < 4; w2++) {
+                    const uint32_t c = wc[u][w2];
+                    if (w2 < (tid >> 6))
+                        mine[u] += c;
+                    total += c;
+                }
+            }
+            if (total) {
 #pragma unroll
                 for (int u = 0; u < TK_U; u++)
-#pragma unroll
-                    for (int w2 = 0; w2 < 4; w2++) {
-                        const uint32_t c = s_wcnt[u][w2];
-                        total += c;
-                        (void)before;
-                    }
-                const uint32_t nc0 = s_ncand, sl0 = s_slen;
-#pragma unroll
-                for (int u = 0; u < TK_U; u++) {
-                    uint32_t off = 0;
-#pragma unroll
-                    for (int u2 = 0; u2 < TK_U; u2++)
-#pragma unroll
-                        for (int w2 = 0; w2 < 4; w2++)
-                            if (u2 < u || (u2 == u && w2 < (tid >> 6)))
-                                off += s_wcnt[u2][w2];
                     if (pass[u]) {
-                        const uint32_t pos = off + (uint32_t)__popcll(bal[u] & ((1ull << (tid & 63)) - 1ull));
-                        s_buf[TK_KCAP + nc0 + pos] = key[u];
-                        if (stream && sl0 + pos < stream_cap)
-                            stream[(size_t)q * stream_cap + sl0 + pos] = key[u];
+                        const uint32_t pos = mine[u] + (uint32_t)__popcll(bal[u] & ((1ull << (tid & 63)) - 1ull));
+                        s_buf[k + ncand + pos] = key[u];
+                        if (stream && slen + pos < stream_cap)
+                            stream[(size_t)q * stream_cap + slen + pos] = key[u];
                     }
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    s_ncand = nc0 + total;
-                    s_slen = sl0 + total;
-                }
+                ncand += total;
+                slen += total;
             }
-            __syncthreads();
+            base += 256 * u_now;
         }
     }
     flush();
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
         keys[(size_t)q * k + j] = v < kKeyInit ? v : kKeyInit;
     }
     if (stream_len && tid == 0)
-        stream_len[q] = s_slen; // > stream_cap: the stream was truncated (the consumer reports it)
+        stream_len[q] = slen; // > stream_cap: the stream was truncated (the consumer reports it)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -217,11 +234,12 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
 // the candidate stream above is such a superset (its filter threshold is never below the heap's current
 // maximum).  One thread per query; faiss Heap.h semantics (1-based binary max-heap on values only).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void heap_replace_top(int k, float *val, long long *ids, float nv, long long nid)
+template <typename ID>
+__device__ __forceinline__ void heap_replace_top(int k, float *val, ID *ids, float nv, ID nid)
 {
     // maxheap_pop followed by maxheap_push, as the reference calls them
     float *v = val - 1;
-    long long *id = ids - 1;
+    ID *id = ids - 1;
     {
         const float last = v[k];
         int hole = 1;
@@ -254,45 +272,84 @@ __device__ __forceinline__ void heap_replace_top(int k, float *val, long long *i
     }
 }
 
-__global__ void heap_replay_kernel(IvfTables t, const Seg *__restrict__ segs, const PlanHdr *__restrict__ hdr, int max_seg,
-                                   const unsigned long long *__restrict__ stream, const uint32_t *__restrict__ stream_len,
-                                   uint32_t stream_cap, int nq, int k, float *__restrict__ dist,
-                                   long long *__restrict__ labels, uint32_t *__restrict__ status)
+// One wavefront per query (four per workgroup).  The heap lives in LDS as (value, scan position); the stream is
+// read 64 keys at a time by all lanes, keys that cannot pass (not below the heap's maximum at the start of the
+// batch -- it only falls) are dropped with one ballot, the rest are replayed in order by lane 0; labels are
+// resolved for the k survivors only, in parallel, at the end.
+__global__ __launch_bounds__(256) void heap_replay_kernel(IvfTables t, const Seg *__restrict__ segs,
+                                                          const PlanHdr *__restrict__ hdr, int max_seg,
+                                                          const unsigned long long *__restrict__ stream,
+                                                          const uint32_t *__restrict__ stream_len, uint32_t stream_cap,
+                                                          int nq, int k, float *__restrict__ dist,
+                                                          long long *__restrict__ labels, uint32_t *__restrict__ status)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + wave;
     if (q >= nq)
-        return;
-    float *val = dist + (size_t)q * k;
-    long long *ids = labels + (size_t)q * k;
-    for (int j = 0; j < k; j++) { // maxheap_heapify
+        return; // whole wavefront; no workgroup barrier below
+    float *val = reinterpret_cast<float *>(smem_h) + (size_t)wave * 2 * k;
+    uint32_t *pos = reinterpret_cast<uint32_t *>(val + k);
+    for (int j = lane; j < k; j += 64) { // maxheap_heapify
         val[j] = FLT_MAX;
-        ids[j] = -1;
+        pos[j] = 0xffffffffu;
     }
     const uint32_t len = stream_len[q];
+    float *out_d = dist + (size_t)q * k;
+    long long *out_l = labels + (size_t)q * k;
     if (len > stream_cap) {
-        atomicOr(status, kStatusTopkStreamOverflow);
+        if (lane == 0)
+            atomicOr(status, kStatusTopkStreamOverflow);
+        for (int j = lane; j < k; j += 64) {
+            out_d[j] = FLT_MAX;
+            out_l[j] = -1;
+        }
         return;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long *st = stream + (size_t)q * stream_cap;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t i = base + lane;
+        unsigned long long key = ~0ull;
+        if (i < len)
+            key = st[i];
+        const float d = orderable_f32((uint32_t)(key >> 32));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // lane 0's heap writes of the previous batch
+        const float top0 = val[0];
+        unsigned long long m = __ballot(i < len && d < top0);
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), b));
+            const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, b);
+            if (lane == 0 && dj < val[0])
+                heap_replace_top<uint32_t>(k, val, pos, dj, pj);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // labels of the survivors (segments ascend in vpos)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t nseg = hdr[q].nseg;
-    const unsigned long long *st = stream + (size_t)q * stream_cap;
-    for (uint32_t i = 0; i < len; i++) {
-        const unsigned long long key = st[i];
-        const float d = orderable_f32((uint32_t)(key >> 32));
-        if (!(d < val[0]))
-            continue;
-        // label of scan position vpos (segments ascend in vpos)
-        const uint32_t vpos = (uint32_t)key;
-        uint32_t a = 0, b = nseg - 1;
-        while (a < b) {
-            const uint32_t mid = (a + b + 1) >> 1;
-            if (sq[mid].vpos <= vpos)
-                a = mid;
-            else
-                b = mid - 1;
+    for (int j = lane; j < k; j += 64) {
+        const uint32_t vpos = pos[j];
+        long long lab = -1;
+        if (vpos != 0xffffffffu && nseg) {
+            uint32_t a = 0, b = nseg - 1;
+            while (a < b) {
+                const uint32_t mid = (a + b + 1) >> 1;
+                if (sq[mid].vpos <= vpos)
+                    a = mid;
+                else
+                    b = mid - 1;
+            }
+            const Seg sg = sq[a];
+            lab = (long long)t.ids[sg.start + (vpos - sg.vpos)];
         }
-        const Seg sg = sq[a];
-        heap_replace_top(k, val, ids, d, (long long)t.ids[sg.start + (vpos - sg.vpos)]);
+        out_d[j] = val[j];
+        out_l[j] = lab;
     }
 }
 
@@ -302,7 +359,7 @@ hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs
 {
     if (nq == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(heap_replay_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, t, segs, hdr, max_seg,
+    hipLaunchKernelGGL(heap_replay_kernel, dim3((nq + 3) / 4), dim3(256), (size_t)4 * 2 * k * sizeof(float), s, t, segs, hdr, max_seg,
                        reinterpret_cast<const unsigned long long *>(stream), stream_len, stream_cap, nq, k, dist,
                        reinterpret_cast<long long *>(labels), status);
     return hipGetLastError();
