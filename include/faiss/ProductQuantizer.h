@@ -27,6 +27,8 @@ struct ProductQuantizer {
 
     /// Lloyd k-means per sub-space (construction side; not on the search path)
     void train(int n, const float *x);
+    /// the same with a chosen number of iterations; warm = keep the current code words as the start
+    void train_iters(int n, const float *x, int niter, bool warm);
     void compute_code(const float *x, uint8_t *code) const;
     void compute_codes(const float *x, uint8_t *codes, size_t n) const;
     void decode(const uint8_t *code, float *x) const;

@@ -36,7 +36,7 @@ struct OPQMatrix : LinearTransform {
     int niter_pq_0;
     size_t max_train_points;
     OPQMatrix(int d = 0, int M = 1, int d2 = -1);
-    /// OPQ learning is construction-side work and is not implemented here
+    /// non-parametric OPQ (alternate PQ training and an orthogonal Procrustes step); construction side, host only
     void train(long n, const float *x) override;
 };
 

@@ -183,18 +183,21 @@ void ProductQuantizer::compute_codes(const float *x, uint8_t *codes, size_t n) c
         compute_code(x + (size_t)i * d, codes + (size_t)i * code_size);
 }
 
-void ProductQuantizer::train(int n, const float *x)
+void ProductQuantizer::train(int n, const float *x) { train_iters(n, x, 25, false); }
+
+void ProductQuantizer::train_iters(int n, const float *x, int niter, bool warm)
 {
     // plain Lloyd iterations per sub-space, seeded with a random subset (construction side)
-    const int niter = 25;
     std::vector<int> perm((size_t)n);
     std::vector<float> sum(ksub * dsub);
     std::vector<size_t> cnt(ksub);
     std::vector<uint32_t> assign((size_t)n);
     for (size_t m = 0; m < M; m++) {
-        rand_perm(perm.data(), (size_t)n, 1234 + (long)m);
-        for (size_t c = 0; c < ksub; c++)
-            std::memcpy(get_centroids(m, c), x + (size_t)perm[c % (size_t)n] * d + m * dsub, dsub * sizeof(float));
+        if (!warm) {
+            rand_perm(perm.data(), (size_t)n, 1234 + (long)m);
+            for (size_t c = 0; c < ksub; c++)
+                std::memcpy(get_centroids(m, c), x + (size_t)perm[c % (size_t)n] * d + m * dsub, dsub * sizeof(float));
+        }
         for (int it = 0; it < niter; it++) {
 #pragma omp parallel for
             for (long i = 0; i < (long)n; i++) {
@@ -276,10 +279,133 @@ OPQMatrix::OPQMatrix(int d, int M_, int d2)
     is_trained = false;
 }
 
-void OPQMatrix::train(long, const float *)
+// One-sided Jacobi SVD of the square matrix c (row major, n x n, overwritten): on return the columns of c are
+// u_j * s_j and v holds V (row major), c = U S V^T.  Plain, slow and enough for d x d with d in the hundreds.
+static void jacobi_svd(std::vector<double> &c, std::vector<double> &v, int n)
 {
-    throw std::runtime_error("OPQMatrix::train: OPQ learning is index construction, outside the MI355X search "
-                             "path (SURVEY.md 8f); load a trained matrix with read_VectorTransform");
+    v.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++)
+        v[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < n; i++) {
+                    const double x = c[(size_t)i * n + p], y = c[(size_t)i * n + q];
+                    a += x * x;
+                    b += y * y;
+                    g += x * y;
+                }
+                if (std::fabs(g) <= 1e-15 * std::sqrt(a * b))
+                    continue;
+                off += std::fabs(g);
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < n; i++) {
+                    const double x = c[(size_t)i * n + p], y = c[(size_t)i * n + q];
+                    c[(size_t)i * n + p] = cs * x - sn * y;
+                    c[(size_t)i * n + q] = sn * x + cs * y;
+                    const double vx = v[(size_t)i * n + p], vy = v[(size_t)i * n + q];
+                    v[(size_t)i * n + p] = cs * vx - sn * vy;
+                    v[(size_t)i * n + q] = sn * vx + cs * vy;
+                }
+            }
+        if (off < 1e-12)
+            break;
+    }
+}
+
+// Non-parametric OPQ (Ge, He, Ke, Sun 2013), the scheme faiss's OPQMatrix::train follows: start from a random
+// rotation, then alternate (a) product quantizer training on the rotated points (niter_pq_0 Lloyd iterations the
+// first time, niter_pq warm-started ones after) and (b) the orthogonal Procrustes step -- the rotation R that
+// minimises sum ||R x_i - y_i||^2 against the decoded points y_i is V U^T for X^T Y = U S V^T.
+// Construction side, host only; faiss's own random streams are not reproduced, so matrices differ from faiss's.
+void OPQMatrix::train(long n_in, const float *x)
+{
+    const int d = d_in;
+    if (d_out != d_in)
+        throw std::runtime_error("OPQMatrix::train: only square rotations (d_out == d_in) are supported");
+    if (M <= 0 || d % M)
+        throw std::runtime_error("OPQMatrix::train: d must be a multiple of M");
+    const size_t n = (size_t)std::min<long>(n_in, (long)max_train_points);
+    if (n < 256)
+        throw std::runtime_error("OPQMatrix::train: needs at least 256 training points");
+    // random orthonormal start: Gram-Schmidt of a seeded Gaussian matrix
+    A.assign((size_t)d * d, 0.f);
+    {
+        std::mt19937 rng(1234);
+        std::normal_distribution<double> gauss(0.0, 1.0);
+        std::vector<double> q((size_t)d * d);
+        for (auto &e : q)
+            e = gauss(rng);
+        for (int i = 0; i < d; i++) {
+            for (int j = 0; j < i; j++) {
+                double dot = 0;
+                for (int k = 0; k < d; k++)
+                    dot += q[(size_t)i * d + k] * q[(size_t)j * d + k];
+                for (int k = 0; k < d; k++)
+                    q[(size_t)i * d + k] -= dot * q[(size_t)j * d + k];
+            }
+            double nrm = 0;
+            for (int k = 0; k < d; k++)
+                nrm += q[(size_t)i * d + k] * q[(size_t)i * d + k];
+            nrm = std::sqrt(nrm);
+            for (int k = 0; k < d; k++)
+                q[(size_t)i * d + k] /= nrm;
+        }
+        for (size_t e = 0; e < q.size(); e++)
+            A[e] = (float)q[e];
+    }
+    have_bias = false;
+    b.clear();
+    ProductQuantizer pq((size_t)d, (size_t)M, 8);
+    std::vector<float> xr(n * d), xd(n * d);
+    std::vector<uint8_t> codes(n * pq.code_size);
+    std::vector<double> c((size_t)d * d), v;
+    for (int it = 0; it < niter; it++) {
+        apply_noalloc((long)n, x, xr.data());
+        pq.train_iters((int)n, xr.data(), it == 0 ? niter_pq_0 : niter_pq, it != 0);
+        pq.compute_codes(xr.data(), codes.data(), n);
+        pq.decode(codes.data(), xd.data(), n);
+        if (verbose) {
+            double err = 0;
+            for (size_t e = 0; e < n * (size_t)d; e++)
+                err += (double)(xr[e] - xd[e]) * (xr[e] - xd[e]);
+            printf("  OPQ iteration %d/%d: quantisation error %.6g\n", it + 1, niter, err / (double)n);
+        }
+        // C = X^T Y (d x d), C[a][b] = sum_i x_i[a] * y_i[b]
+        std::fill(c.begin(), c.end(), 0.0);
+#pragma omp parallel for
+        for (int a = 0; a < d; a++)
+            for (size_t i = 0; i < n; i++) {
+                const double xa = x[i * d + a];
+                const float *yi = xd.data() + i * d;
+                double *row = c.data() + (size_t)a * d;
+                for (int bb = 0; bb < d; bb++)
+                    row[bb] += xa * yi[bb];
+            }
+        jacobi_svd(c, v, d); // columns of c: u_j * s_j
+        // R = V U^T: R[i][k] = sum_j V[i][j] * U[k][j]
+        for (int j = 0; j < d; j++) {
+            double s = 0;
+            for (int k = 0; k < d; k++)
+                s += c[(size_t)k * d + j] * c[(size_t)k * d + j];
+            s = std::sqrt(s);
+            if (s > 0)
+                for (int k = 0; k < d; k++)
+                    c[(size_t)k * d + j] /= s;
+        }
+        for (int i = 0; i < d; i++)
+            for (int k = 0; k < d; k++) {
+                double r = 0;
+                for (int j = 0; j < d; j++)
+                    r += v[(size_t)i * d + j] * c[(size_t)k * d + j];
+                A[(size_t)i * d + k] = (float)r;
+            }
+    }
+    is_trained = true;
 }
 
 // ---------------------------------------------------------------------------------------------- file I/O

@@ -1,12 +1,14 @@
 // ivfhnsw::IndexIVF_HNSW_Grouping over the MI355X C ABI (include/ivf-hnsw/IndexIVF_HNSW_Grouping.h).
 // search runs on the device (plan_grouping_kernel + the ADC scan); read/write keep the reference's Grouping
 // .index layout (IndexIVF_HNSW_Grouping.cpp:397-483).  add_group / train_pq (index construction) are outside
-// the search path; add_group runs on the device, code book training is not built.
+// the search path; add_group runs on the device, train_pq (code book training) on the host.
 #include <ivf-hnsw/IndexIVF_HNSW_Grouping.h>
 
 #include <ivfhnsw_hip.h>
 
 #include <algorithm>
+#include <iostream>
+#include <map>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -219,14 +221,100 @@ void IndexIVF_HNSW_Grouping::add_group(size_t centroid_idx, size_t group_size, c
     device_dirty_ = true;
 }
 
-static void not_built(const char *what)
+// train_pq (Grouping.cpp:486-618): residuals against the SUB-centroids of a training sample, then the two code
+// books.  Host code (code book training is not on the device); the assignment of the sample runs on the device.
+void IndexIVF_HNSW_Grouping::train_pq(size_t n, const float *x)
 {
-    throw std::runtime_error(std::string("IndexIVF_HNSW_Grouping::") + what +
-                             ": code book training for the Grouping index is not implemented (SURVEY.md 8f rank 4); "
-                             "load trained code books with read_ProductQuantizer");
-}
+    std::vector<idx_t> assigned(n);
+    assign(n, x, assigned.data());
+    std::map<idx_t, std::vector<size_t>> groups; // ordered, so that a run is reproducible (the reference's is not)
+    for (size_t i = 0; i < n; i++)
+        groups[assigned[i]].push_back(i);
 
-void IndexIVF_HNSW_Grouping::train_pq(size_t, const float *) { not_built("train_pq"); }
+    std::vector<float> train_subcentroids, train_residuals;
+    train_subcentroids.reserve(n * d);
+    train_residuals.reserve(n * d);
+    std::vector<size_t> group_sizes;
+    std::cout << "Training Residual PQ codebook " << std::endl;
+    for (const auto &grp : groups) {
+        const idx_t centroid_idx = grp.first;
+        const float *centroid = quantizer->getDataByInternalId(centroid_idx);
+        const size_t group_size = grp.second.size();
+        std::vector<float> data(group_size * d);
+        for (size_t i = 0; i < group_size; i++)
+            std::memcpy(&data[i * d], x + grp.second[i] * d, d * sizeof(float));
+        // :507-517 neighbour centroids, nearest dropped
+        std::vector<idx_t> nn(nsubc);
+        std::vector<float> cv_norms(nsubc);
+        auto raw = quantizer->searchKnn(centroid, nsubc + 1);
+        while (raw.size() > 1) {
+            cv_norms[raw.size() - 2] = raw.top().first;
+            nn[raw.size() - 2] = raw.top().second;
+            raw.pop();
+        }
+        std::vector<float> cvs(nsubc * d), subc(nsubc * d);
+        for (size_t s2 = 0; s2 < nsubc; s2++)
+            faiss::fvec_madd(d, quantizer->getDataByInternalId(nn[s2]), -1.f, centroid, &cvs[s2 * d]);
+        const float alpha = compute_alpha(cvs.data(), data.data(), centroid, cv_norms.data(), group_size);
+        for (size_t s2 = 0; s2 < nsubc; s2++)
+            faiss::fvec_madd(d, centroid, alpha, &cvs[s2 * d], &subc[s2 * d]);
+        std::vector<idx_t> sidx(group_size);
+        compute_subcentroid_idxs(sidx.data(), subc.data(), data.data(), group_size);
+        std::vector<float> res(group_size * d);
+        compute_residuals(group_size, data.data(), res.data(), subc.data(), sidx.data());
+        for (size_t i = 0; i < group_size; i++) {
+            train_subcentroids.insert(train_subcentroids.end(), &subc[(size_t)sidx[i] * d], &subc[(size_t)sidx[i] * d] + d);
+            train_residuals.insert(train_residuals.end(), &res[i * d], &res[i * d] + d);
+        }
+        group_sizes.push_back(group_size);
+    }
+    if (do_opq) { // :555-569
+        faiss::OPQMatrix *matrix = new faiss::OPQMatrix((int)d, (int)pq->M);
+        std::cout << "Training OPQ Matrix" << std::endl;
+        matrix->verbose = true;
+        matrix->max_train_points = n;
+        matrix->niter = 100;
+        try {
+            matrix->train((long)n, train_residuals.data());
+        } catch (...) {
+            delete matrix;
+            throw;
+        }
+        opq_matrix = matrix;
+        std::vector<float> copy(train_residuals);
+        opq_matrix->apply_noalloc((long)n, copy.data(), train_residuals.data());
+    }
+    printf("Training %zdx%zd PQ on %zd vectors in %zdD\n", pq->M, pq->ksub, train_residuals.size() / d, d);
+    pq->verbose = true;
+    pq->train((int)n, train_residuals.data());
+
+    // :577-617 norm code book from the reconstructed training points
+    std::cout << "Training Norm PQ codebook " << std::endl;
+    std::vector<float> train_norms;
+    train_norms.reserve(n);
+    size_t off = 0;
+    for (const size_t group_size : group_sizes) {
+        const float *res = train_residuals.data() + off * d, *sub = train_subcentroids.data() + off * d;
+        std::vector<uint8_t> xcodes(group_size * code_size);
+        pq->compute_codes(res, xcodes.data(), group_size);
+        std::vector<float> dec(group_size * d);
+        pq->decode(xcodes.data(), dec.data(), group_size);
+        if (do_opq) {
+            std::vector<float> copy(dec);
+            opq_matrix->transform_transpose((long)group_size, copy.data(), dec.data());
+        }
+        std::vector<float> rec(group_size * d), norms(group_size);
+        for (size_t i = 0; i < group_size; i++)
+            faiss::fvec_madd(d, &dec[i * d], 1.f, sub + i * d, &rec[i * d]);
+        faiss::fvec_norms_L2sqr(norms.data(), rec.data(), d, group_size);
+        train_norms.insert(train_norms.end(), norms.begin(), norms.end());
+        off += group_size;
+    }
+    printf("Training %zdx%zd PQ on %zd vectors in 1D\n", norm_pq->M, norm_pq->ksub, train_norms.size());
+    norm_pq->verbose = true;
+    norm_pq->train((int)n, train_norms.data());
+    device_dirty_ = true;
+}
 
 // The per-group helpers of the reference (:655-733) as host functions, for callers that use them directly; add_group
 // does not go through them.

@@ -177,6 +177,60 @@ static int run(int argc, char **argv)
         delete index;
         return 0;
     }
+    if (cmd == "opq_train" && argc == 8) {
+        // OPQMatrix::train on the rows of an .fvecs file; prints the quantisation error of a PQ trained on the raw
+        // points and of one trained on the rotated points, writes the matrix
+        const size_t d = atol(argv[2]), M = atol(argv[3]), n = atol(argv[4]);
+        const int niter = atoi(argv[6]);
+        std::vector<float> x(n * d);
+        {
+            std::ifstream in(argv[5], std::ios::binary);
+            readXvec<float>(in, x.data(), d, n);
+        }
+        auto pq_error = [&](const float *pts) {
+            faiss::ProductQuantizer pq(d, M, 8);
+            pq.train((int)n, pts);
+            std::vector<uint8_t> codes(n * pq.code_size);
+            pq.compute_codes(pts, codes.data(), n);
+            std::vector<float> dec(n * d);
+            pq.decode(codes.data(), dec.data(), n);
+            double e = 0;
+            for (size_t i = 0; i < n * d; i++)
+                e += (double)(pts[i] - dec[i]) * (pts[i] - dec[i]);
+            return e / (double)n;
+        };
+        faiss::OPQMatrix opq((int)d, (int)M);
+        opq.niter = niter;
+        opq.niter_pq_0 = 10;
+        opq.niter_pq = 3;
+        opq.max_train_points = n;
+        opq.train((long)n, x.data());
+        std::vector<float> xr(n * d);
+        opq.apply_noalloc((long)n, x.data(), xr.data());
+        printf("err_plain %.9g\nerr_opq %.9g\n", pq_error(x.data()), pq_error(xr.data()));
+        faiss::write_VectorTransform(&opq, argv[7]);
+        return 0;
+    }
+    if (cmd == "grouping_train" && argc == 13) {
+        // IndexIVF_HNSW_Grouping::train_pq on a training sample, code books written in faiss's formats
+        const size_t d = atol(argv[2]), nc = atol(argv[3]), cs = atol(argv[4]), nsubc = atol(argv[5]);
+        const char *centroids = argv[6], *info = argv[7], *edges = argv[8], *plearn = argv[9];
+        const size_t n = atol(argv[10]);
+        IndexIVF_HNSW_Grouping *index = new IndexIVF_HNSW_Grouping(d, nc, cs, 8, nsubc);
+        index->build_quantizer(centroids, info, edges, 16, 500);
+        index->quantizer->efSearch = 40;
+        index->do_opq = false;
+        std::vector<float> x(n * d);
+        {
+            std::ifstream in(plearn, std::ios::binary);
+            readXvec<float>(in, x.data(), d, n);
+        }
+        index->train_pq(n, x.data());
+        faiss::write_ProductQuantizer(index->pq, argv[11]);
+        faiss::write_ProductQuantizer(index->norm_pq, argv[12]);
+        delete index;
+        return 0;
+    }
     if (cmd == "search" && argc == 22) {
         const bool grp = !strcmp(argv[2], "grouping");
         const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);

@@ -4,6 +4,7 @@ through the classes against the oracle (GPU), and -- when the reference tree is 
 reference's OWN driver binary, built unchanged against these headers, run end to end (GPU)."""
 import os
 import re
+import struct
 import subprocess
 
 import numpy as np
@@ -191,3 +192,50 @@ def test_reference_driver_binary_runs_on_this_library(tmp_path, driver, opq):
     m = re.search(r"Recall@1: ([0-9.eE+-]+)", r.stdout)
     assert m, r.stdout[-2000:]
     assert abs(float(m.group(1)) - want) < 1e-6, (m.group(1), want)
+
+
+# ---------------------------------------------------------------------------------------------- training (host)
+def test_opq_training_gives_a_rotation_that_helps(tmp_path):
+    """OPQMatrix::train (host): on points whose variance is mixed across sub-spaces the learnt matrix must be
+    orthonormal and the product quantizer trained behind it must beat the one trained on the raw points."""
+    rng = np.random.default_rng(31)
+    d, M, n = 32, 4, 4000
+    z = rng.normal(size=(n, d)) * np.linspace(6.0, 0.2, d)        # strongly unequal variances ...
+    mix = synth.random_rotation(rng, d)
+    x = (z @ mix.T).astype(np.float32)                            # ... smeared over all coordinates
+    px, pv = str(tmp_path / "x.fvecs"), str(tmp_path / "opq.vt")
+    hostio.write_xvecs(px, x)
+    r = tool("opq_train", d, M, n, px, 12, pv)
+    err = dict(l.split() for l in r.stdout.splitlines() if l.startswith("err_"))
+    assert float(err["err_opq"]) < 0.9 * float(err["err_plain"]), r.stdout
+    raw = open(pv, "rb").read()
+    assert raw[:4] == b"LTra"
+    cnt = struct.unpack("<Q", raw[5:13])[0]
+    assert cnt == d * d
+    A = np.frombuffer(raw[13:13 + 4 * d * d], np.float32).reshape(d, d).astype(np.float64)
+    assert np.abs(A @ A.T - np.eye(d)).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_grouping_train_pq_writes_usable_code_books(tmp_path):
+    """IndexIVF_HNSW_Grouping::train_pq (assignment on the device, training on the host): the residual code book
+    must quantise the training residuals far better than the points themselves, the norm code book must be 256
+    finite values around the squared norms."""
+    rng = np.random.default_rng(32)
+    d, M, nc, nsubc, n = 32, 4, 64, 4, 3000
+    cents = synth.sift_like(rng, nc, d)
+    x = (cents[rng.integers(0, nc, size=n)] + rng.normal(0, 6.0, size=(n, d))).astype(np.float32)
+    p = {k: str(tmp_path / v) for k, v in dict(cent="c.fvecs", info="i", edges="e", x="x.fvecs", pq="pq", npq="npq").items()}
+    hostio.write_xvecs(p["cent"], cents)
+    hostio.write_xvecs(p["x"], x)
+    tool("grouping_train", d, nc, M, nsubc, p["cent"], p["info"], p["edges"], p["x"], n, p["pq"], p["npq"])
+    raw = open(p["pq"], "rb").read()
+    hd = struct.unpack("<QQQQ", raw[:32])
+    assert hd == (d, M, 8, d * 256)
+    cb = np.frombuffer(raw[32:], np.float32).reshape(M, 256, d // M)
+    assert np.isfinite(cb).all() and np.abs(cb).max() < 100        # residual scale, not data scale
+    rawn = open(p["npq"], "rb").read()
+    assert struct.unpack("<QQQQ", rawn[:32]) == (1, 1, 8, 256)
+    nt = np.frombuffer(rawn[32:], np.float32)
+    norms = (x.astype(np.float64) ** 2).sum(1)
+    assert np.isfinite(nt).all() and nt.min() > 0.3 * norms.min() and nt.max() < 3 * norms.max()
