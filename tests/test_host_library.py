@@ -21,7 +21,10 @@ REF_DRV = os.path.join(ROOT, "oracle", "_ref")
 
 def tool(*args):
     assert os.path.exists(TOOL), "run __graft_entry__.build()"
-    r = subprocess.run([TOOL] + [str(a) for a in args], capture_output=True, text=True)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(min(8, len(os.sched_getaffinity(0)))))  # a CPU quota makes wide teams crawl
+    env.setdefault("OMP_WAIT_POLICY", "passive")
+    r = subprocess.run([TOOL] + [str(a) for a in args], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return r
 
