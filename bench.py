@@ -126,8 +126,6 @@ def main():
         # for a throughput corpus the synthetic centroids simply ARE the rotated ones
         opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
     if grouping:
-        if world != 1:
-            raise SystemExit("the grouping workload is single-GPU for now")
         gt = synth.make_grouping_tables(args.seed + 3, tb, 64, device=dev)
         opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
         # the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800)
@@ -160,7 +158,7 @@ def main():
         else:
             # coarse walk for this rank's slice of the batch -> all-gather -> scan own shard for all queries ->
             # MIN over shards of the packed keys -> owner resolves labels -> MAX over shards
-            sharded.step(d_q, d_dist, d_lab, max_codes, ef)
+            sharded.step(d_q, d_dist, d_lab, max_codes, ef, do_pruning=grouping)
 
     def barrier():
         torch.cuda.synchronize()

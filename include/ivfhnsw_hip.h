@@ -143,6 +143,10 @@ int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int6
 int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, size_t nprobe, size_t efSearch,
                            uint32_t *d_coarse_ids, float *d_coarse_dists);
 
+/* opq_matrix->apply (IndexIVF_HNSW.cpp:240) alone, device pointers: d_out[q] = A * d_queries[q].  A plain copy
+ * when the index holds no OPQ matrix.  For callers that run the coarse stage themselves (sharded search). */
+int ivfhnsw_gpu_rotate_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, float *d_out);
+
 /* Host-pointer form of the coarse stage; with k = 1 this is IndexIVF_HNSW::assign
  * (IndexIVF_HNSW.cpp:68-72) for n vectors.  The OPQ rotation is NOT applied (assign() takes vectors in
  * the graph's space).  Slots beyond the number of nodes found hold 0xffffffff / 0. */

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
-    "ivfhnsw_gpu_encode_groups",
+    "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev",
 )
 
 
@@ -90,6 +90,7 @@ def lib():
                                          C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_encode_groups.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_rotate_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_get_stage_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
@@ -222,6 +223,10 @@ class GpuIndex:
     def resolve_keys_dev(self, nq, k, d_keys, d_distances, d_labels):
         _check(lib().ivfhnsw_gpu_resolve_keys_dev(self._h, nq, k, _devptr(d_keys), _devptr(d_distances),
                                                   _devptr(d_labels)))
+
+    def rotate_dev(self, nq, d_queries, d_out):
+        """opq_matrix->apply on device buffers (a copy when the index has no OPQ matrix)."""
+        _check(lib().ivfhnsw_gpu_rotate_dev(self._h, nq, _devptr(d_queries), _devptr(d_out)))
 
     def coarse_dev(self, nq, d_queries, nprobe, efSearch, d_coarse_ids, d_coarse_dists):
         _check(lib().ivfhnsw_gpu_coarse_dev(self._h, nq, _devptr(d_queries), nprobe, efSearch,

@@ -286,7 +286,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 4; }
+int ivfhnsw_gpu_abi_version(void) { return 5; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
@@ -644,6 +644,26 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
                               d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
                               h->w_status.as<uint32_t>() + 1));
+    }
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_rotate_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, float *d_out)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "rotate needs upload_ivf");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!d_queries || !d_out || nq > 0x7fffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer or nq too large");
+    if (h->t.opq_At) {
+        StageScope sc(h, IVFHNSW_STAGE_OPQ);
+        HIP_TRY(launch_opq(h->stream, h->t.opq_At, d_queries, d_out, (int)nq, h->t.d));
+    } else if (d_out != d_queries) {
+        HIP_TRY(hipMemcpyAsync(d_out, d_queries, nq * (size_t)h->t.d * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     }
     return IVFHNSW_OK;
 }

@@ -89,14 +89,20 @@ class ShardedSearcher:
         self.cid = torch.empty((self.per * world, nprobe), dtype=torch.int32, device=device)
         self.cd = torch.empty((self.per * world, nprobe), dtype=torch.float32, device=device)
         self.keys = torch.empty((nq, 1), dtype=torch.int64, device=device)
+        self.xrot = None  # own slice of the batch, OPQ-rotated for the coarse walk (allocated on first use)
 
     def step(self, d_q, d_dist, d_lab, max_codes, efSearch, do_pruning=False):
         """One batch: coarse slice -> all-gather -> scan own shard -> MIN keys -> resolve -> MAX labels.
-        (OPQ: d_q must already be rotated for the coarse slice; the bench workload has no OPQ.)"""
+        With OPQ the walk runs on the rotated slice (IndexIVF_HNSW.cpp:240,248); search_dev rotates the whole batch
+        again for its tables, from the unrotated d_q."""
+        import torch
         import torch.distributed as dist
         g, r, per = self.g, self.rank, self.per
         if self.hi > self.lo:
-            g.coarse_dev(self.hi - self.lo, d_q[self.lo:self.hi], self.nprobe, efSearch,
+            if self.xrot is None:
+                self.xrot = torch.empty((per, d_q.shape[1]), dtype=torch.float32, device=d_q.device)
+            g.rotate_dev(self.hi - self.lo, d_q[self.lo:self.hi], self.xrot)
+            g.coarse_dev(self.hi - self.lo, self.xrot, self.nprobe, efSearch,
                          self.cid[r * per:], self.cd[r * per:])
         if self.world > 1:
             _all_gather_rows(self.cid, r, per, self.group)

@@ -104,3 +104,34 @@ def test_sharded_device_generated_corpus(gpu):
         label = torch.maximum(label, ll)
     assert np.array_equal(label.cpu().numpy(), ref_l)
     assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("nsubc", [0, 8])
+def test_sharded_searcher_step_with_opq(gpu, pkg, nsubc):
+    """ShardedSearcher.step on one rank (no collectives) with an OPQ index: the walk must run on the rotated slice
+    (ivfhnsw_gpu_rotate_dev), the tables on the rotated batch -- labels and distances of the oracle."""
+    import importlib
+    import torch
+    pkg_dist = importlib.import_module("ivfhnsw_amd.distributed")
+    c = corpus(seed=43, nc=256, d=96, M=8, n_base=20000, nq=80, nsubc=nsubc, opq=True)
+    nprobe, max_codes, ef = 16, 2000, 48
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=bool(nsubc))
+    ref_d, ref_l, _, _, _ = ox.search_batch(c["queries"], k=1)
+    g = gpu()
+    g.upload_ivf(c["d"], c["code_size"], c["offsets"], c["ids"], c["codes"], c["norm_codes"], c["centroid_norms"],
+                 c["pq_centroids"], c["norm_table"], opq_A=c["opq_A"])
+    gr = c["graph"]
+    g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+    if nsubc:
+        g.upload_grouping(nsubc, c["alphas"], c["nn_centroid_idxs"], c["subgroup_sizes"], c["inter_centroid_dists"])
+    dev = torch.device("cuda", 0)
+    nq = len(ref_l)
+    d_q = torch.from_numpy(c["queries"]).to(dev)
+    dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
+    ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    s = pkg_dist.ShardedSearcher(g, 0, 1, nq, nprobe, dev)
+    s.step(d_q, dd, ll, max_codes, ef, do_pruning=bool(nsubc))
+    g.sync()
+    assert np.array_equal(ll.cpu().numpy(), ref_l)
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
