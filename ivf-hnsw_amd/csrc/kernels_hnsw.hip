@@ -179,7 +179,13 @@ template <int NCH> struct RSet {
 // coalesced rate).
 // The bucket count follows the occupancy the kernel is built for (MINW waves per SIMD, 4 * MINW per CU sharing
 // 160 KB of LDS): 7 KB of buckets at 4 (with the merge buffer below that is 10 KB per wave), 6 KB at 5, 5 KB at 6.
-constexpr int vis_buckets(int minw) { return minw <= 4 ? 896 : minw == 5 ? 768 : minw <= 7 ? 640 : 384; }
+constexpr int vis_buckets(int minw, int tagw = 8)
+{
+    // 10-bit tags (six per bucket) exist for graphs of about a million nodes -- the reference's 993 127 centroids,
+    // the 2^20 of the 8-GPU bench: with 12-bit tags (five per bucket) 896 buckets ran 56 % full and every
+    // expansion paid a global atomic for an overflowing neighbour.  1040 buckets x 6 = 6240 slots, 8320 bytes.
+    return minw <= 4 ? (tagw == 10 ? 1040 : 896) : minw == 5 ? 768 : minw <= 7 ? 640 : 384;
+}
 
 // TAGW = bits per tag: 8 (8 tags per bucket, graphs up to 255 * 1024 nodes), 12 (5 per bucket, up to 4095 * 1024),
 // 16 (4 per bucket, up to 65535 * 1024); 0 = no LDS set, global bitmap only.  Fields are scanned SWAR-style:
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     // neighbour-row form: the same in 1/256 steps, four byte planes of 32 words (hi, lo, XL, XH)
     uint32_t *s_q8 = reinterpret_cast<uint32_t *>(s_qp + dp);
     unsigned long long *tail = reinterpret_cast<unsigned long long *>(smem + (size_t)(g.d + dp) * sizeof(float) + 512);
-    constexpr int NB = vis_buckets(MINW);
+    constexpr int NB = vis_buckets(MINW, TAGW);
     unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0}, st_t = 0;
     // the tail doubles as the merge buffer of a pass's admissions (ef + 8 entries; only used while the tail is empty)
     const int merge_extra = (NCH <= 4 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0;
@@ -809,13 +815,28 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
         return (v == 5 || v == 6) ? v : 4;
     }();
     const int nch = (ef + 63) / 64;
-    const uint32_t nbk = (uint32_t)vis_buckets((nch <= 4 && g.nbrows) ? occ : 4);
+    const int occ_eff = (nch <= 4 && g.nbrows) ? occ : 4;
+    uint32_t nbk = (uint32_t)vis_buckets(occ_eff);
     // the LDS visited set needs 16-bit tags at most; IVFHNSW_WALK_VIS=bitmap forces the global bitmap (A/B runs)
     static const bool force_bitmap = [] {
         const char *e = getenv("IVFHNSW_WALK_VIS");
         return e && e[0] == 'b';
     }();
-    const int tagw = force_bitmap ? 0 : g.n <= 255u * nbk ? 8 : g.n <= 4095u * nbk ? 12 : g.n <= 65535u * nbk ? 16 : 0;
+    int tagw = force_bitmap ? 0 : g.n <= 255u * nbk ? 8 : g.n <= 4095u * nbk ? 12 : g.n <= 65535u * nbk ? 16 : 0;
+    // IVFHNSW_WALK_TAGW=10|12|16 forces a wider tag than the graph needs (tests: small graphs reach every form)
+    static const int force_tagw = [] {
+        const char *e = getenv("IVFHNSW_WALK_TAGW");
+        const int v = e ? atoi(e) : 0;
+        return (v == 10 || v == 12 || v == 16) ? v : 0;
+    }();
+    if (tagw && force_tagw > tagw)
+        tagw = force_tagw;
+    if ((tagw == 12 || tagw == 10) && occ_eff == 4 && g.n <= 1023u * (uint32_t)vis_buckets(4, 10) && force_tagw != 12) {
+        tagw = 10;
+        nbk = (uint32_t)vis_buckets(4, 10);
+    } else if (tagw == 10) {
+        tagw = 12; // the 10-bit form exists for 4 waves per SIMD only
+    }
     // occupancy experiments only: extra LDS per wavefront lowers the number of resident waves
     static const size_t lds_pad = [] {
         const char *e = getenv("IVFHNSW_WALK_LDSPAD");
@@ -842,6 +863,8 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
     do {                               \
         if (tagw == 8)                 \
             IVFHNSW_WALK_T(N, W, 8);   \
+        else if (tagw == 10)           \
+            IVFHNSW_WALK_T(N, 4, 10);  \
         else if (tagw == 12)           \
             IVFHNSW_WALK_T(N, W, 12);  \
         else if (tagw == 16)           \
