@@ -1044,7 +1044,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     // 4. table (IndexIVF_HNSW.cpp:262)
     {
         StageScope sc(h, IVFHNSW_STAGE_LUT);
-        HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq));
+        HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq, h->w_hdr.as<PlanHdr>()));
     }
     // 5. scan (IndexIVF_HNSW.cpp:282-289)
     const bool heap = p->heap_order && k > 1;

@@ -77,7 +77,8 @@ struct GraphTables {
 // y[q][i] = fmaf chain over k of A[i][k] * x[q][k]  (IndexIVF_HNSW.cpp:240)
 hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, int nq, int d);
 // tab[q][m][c] = <x_m, centroid[m][c]>  (IndexIVF_HNSW.cpp:262)
-hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq);
+// hdr (optional): queries whose plan is empty on this shard get no table
+hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq, const PlanHdr *hdr = nullptr);
 // probe order + max_codes rule (IndexIVF_HNSW.cpp:267-292); also resets keys[nq*k] to kKeyInit
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids,
                            const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs,

@@ -121,12 +121,24 @@ __device__ __forceinline__ float ip_sse_order(const float *x, const float *y, in
 
 template <int DSUB>
 __global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, const float *__restrict__ cb,
-                                                  float *__restrict__ luts, int nq, int d, int M, int dsub_rt)
+                                                  float *__restrict__ luts, int nq, int d, int M, int dsub_rt,
+                                                  const PlanHdr *__restrict__ hdr)
 {
     extern __shared__ float s_q[]; // [LUT_QB][d]
     const int dsub = DSUB > 0 ? DSUB : dsub_rt;
     const int q0 = blockIdx.x * LUT_QB;
     const int nqb = min(LUT_QB, nq - q0);
+    // a shard scores nothing for a query none of whose scanned lists it owns (16 % of the queries at 8 shards):
+    // no table needed
+    bool need[LUT_QB];
+    bool any = false;
+#pragma unroll
+    for (int qi = 0; qi < LUT_QB; qi++) {
+        need[qi] = qi < nqb && (!hdr || hdr[q0 + qi].total != 0);
+        any |= need[qi];
+    }
+    if (!any)
+        return;
     for (int i = threadIdx.x; i < nqb * d; i += 256)
         s_q[i] = xq[(size_t)q0 * d + i];
     __syncthreads();
@@ -145,29 +157,32 @@ __global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, 
             for (int i = 0; i < dsub; i++)
                 row[i] = src[i];
         }
-        for (int qi = 0; qi < nqb; qi++) {
+#pragma unroll
+        for (int qi = 0; qi < LUT_QB; qi++) {
+            if (!need[qi])
+                continue;
             float r = ip_sse_order<DSUB>(s_q + qi * d + m * dsub, row, dsub);
             luts[((size_t)(q0 + qi) * M + m) * 256 + c] = r;
         }
     }
 }
 
-hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq)
+hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq, const PlanHdr *hdr)
 {
     if (nq == 0)
         return hipSuccess;
     dim3 grid((nq + LUT_QB - 1) / LUT_QB), block(256);
     size_t shm = (size_t)LUT_QB * t.d * sizeof(float);
     switch (t.dsub) {
-    case 4: hipLaunchKernelGGL(lut_kernel<4>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
-    case 6: hipLaunchKernelGGL(lut_kernel<6>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
-    case 8: hipLaunchKernelGGL(lut_kernel<8>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
-    case 12: hipLaunchKernelGGL(lut_kernel<12>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
-    case 16: hipLaunchKernelGGL(lut_kernel<16>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub); break;
+    case 4: hipLaunchKernelGGL(lut_kernel<4>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr); break;
+    case 6: hipLaunchKernelGGL(lut_kernel<6>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr); break;
+    case 8: hipLaunchKernelGGL(lut_kernel<8>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr); break;
+    case 12: hipLaunchKernelGGL(lut_kernel<12>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr); break;
+    case 16: hipLaunchKernelGGL(lut_kernel<16>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr); break;
     default:
         if (t.dsub > 64)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(lut_kernel<0>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub);
+        hipLaunchKernelGGL(lut_kernel<0>, grid, block, shm, s, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, hdr);
     }
     return hipGetLastError();
 }
