@@ -198,6 +198,35 @@ __device__ __forceinline__ float l2_ref_order_oct(const float *row, const float 
     return r;
 }
 
+// The 128-dimensional case with the lane's sixteen query components (q[8j + t]) held in registers for the whole
+// query instead of being read from LDS for every pass: same loads, same order, same sum.
+__device__ __forceinline__ float l2_ref_order_oct128(const float *row, const float (&qr)[16], int t)
+{
+    const float *r1 = row + t;
+    float y[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        y[i] = r1[8 * i];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float d0 = __fsub_rn(qr[i], y[i]);
+        acc = __fadd_rn(acc, __fmul_rn(d0, d0));
+    }
+    const float mir = __uint_as_float(
+        (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(acc), 0x141, 0xf, 0xf, true));
+    float r = __fadd_rn(quad_bcast<0>(acc), quad_bcast<1>(acc));
+    r = __fadd_rn(r, quad_bcast<2>(acc));
+    r = __fadd_rn(r, quad_bcast<3>(acc));
+    r = __fadd_rn(r, quad_bcast<3>(mir));
+    r = __fadd_rn(r, quad_bcast<2>(mir));
+    r = __fadd_rn(r, quad_bcast<1>(mir));
+    r = __fadd_rn(r, quad_bcast<0>(mir));
+    return r;
+}
+
 // the reference's left-to-right sum of its eight accumulators, held two per lane by a quad (lane t: 2t, 2t+1)
 __device__ __forceinline__ float quad_sum8(float alo, float ahi)
 {

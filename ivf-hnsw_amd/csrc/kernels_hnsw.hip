@@ -342,6 +342,12 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
         __syncthreads(); // also orders the bitmap reset before the atomics below
+        // d = 128 (SIFT): the lane's share of the query for the 8-lanes-per-row distance stays in registers
+        const bool d128 = g.d == 128;
+        float q_reg[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            q_reg[i] = d128 ? s_q[8 * i + (lane & 7)] : 0.f;
         // slack of the rejection test in byte-row units: quantisation error of the worst row, plus what the
         // rounding of s_qp can move a distance by (<= 2^-22 ||q'||; 2^-18 leaves a factor 16)
         float pf_slack = 0.f, pf_slack_q = 0.f, pf_bonus = 0.f;
@@ -633,7 +639,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
                 float dq = 0.f;
                 if (active)
-                    dq = l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                    dq = d128 ? l2_ref_order_oct128(g.vectors + (size_t)nbq * 128, q_reg, lane & 7)
+                              : l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
                 if (STAMPS) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t = walk_stamp();
