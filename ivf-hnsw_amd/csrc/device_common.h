@@ -198,20 +198,21 @@ __device__ __forceinline__ float l2_ref_order_oct(const float *row, const float 
     return r;
 }
 
-// The 128-dimensional case with the lane's sixteen query components (q[8j + t]) held in registers for the whole
+// d = 8 * NJ (128: SIFT, 96: DEEP) with the lane's NJ query components (q[8j + t]) held in registers for the whole
 // query instead of being read from LDS for every pass: same loads, same order, same sum.
-__device__ __forceinline__ float l2_ref_order_oct128(const float *row, const float (&qr)[16], int t)
+template <int NJ>
+__device__ __forceinline__ float l2_ref_order_oct_regs(const float *row, const float (&qr)[16], int t)
 {
     const float *r1 = row + t;
-    float y[16];
+    float y[NJ];
 #pragma unroll
-    for (int i = 0; i < 16; i++)
+    for (int i = 0; i < NJ; i++)
         y[i] = r1[8 * i];
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < NJ; i++) {
         const float d0 = __fsub_rn(qr[i], y[i]);
         acc = __fadd_rn(acc, __fmul_rn(d0, d0));
     }

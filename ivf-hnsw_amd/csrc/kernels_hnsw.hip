@@ -342,12 +342,12 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
         __syncthreads(); // also orders the bitmap reset before the atomics below
-        // d = 128 (SIFT): the lane's share of the query for the 8-lanes-per-row distance stays in registers
-        const bool d128 = g.d == 128;
+        // d = 128 (SIFT) and 96 (DEEP): the lane's share of the query for the 8-lanes-per-row distance stays in
+        // registers (one LDS round trip less in every expansion's dependent chain)
         float q_reg[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
-            q_reg[i] = d128 ? s_q[8 * i + (lane & 7)] : 0.f;
+            q_reg[i] = (g.d == 128 || g.d == 96) && 8 * i < g.d ? s_q[8 * i + (lane & 7)] : 0.f;
         // slack of the rejection test in byte-row units: quantisation error of the worst row, plus what the
         // rounding of s_qp can move a distance by (<= 2^-22 ||q'||; 2^-18 leaves a factor 16)
         float pf_slack = 0.f, pf_slack_q = 0.f, pf_bonus = 0.f;
@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         int x_const = 0;    // 255 * sum XH
         bool x_any = false; // some component of this query lies outside the byte range
         bool x_hi = false;  // ... above it (the XH plane is not all zero)
+        uint4 qp_h = make_uint4(0u, 0u, 0u, 0u), qp_l = qp_h, qp_x = qp_h;
         if (prefilter) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
@@ -423,6 +424,9 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 pf_slack_q = 1.001f * sqrtf(dq_sq);
                 pf_bonus = 0.999f * bonus;
                 __syncthreads();
+                qp_h = *reinterpret_cast<const uint4 *>(s_q8 + 4 * (lane & 7));
+                qp_l = *reinterpret_cast<const uint4 *>(s_q8 + 32 + 4 * (lane & 7));
+                qp_x = *reinterpret_cast<const uint4 *>(s_q8 + 64 + 4 * (lane & 7));
             }
         }
 
@@ -527,14 +531,13 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             if (filter_now && inline_rows) {
                 // (see the gather form below for the bound)  Link lane L is row L of the node's block.
                 const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
-                const uint4 qhv = *reinterpret_cast<const uint4 *>(s_q8 + 4 * (lane & 7));
-                const uint4 qlv = *reinterpret_cast<const uint4 *>(s_q8 + 32 + 4 * (lane & 7));
-                const uint32_t qh[4] = {qhv.x, qhv.y, qhv.z, qhv.w}, ql[4] = {qlv.x, qlv.y, qlv.z, qlv.w};
-                uint32_t xl[4] = {0u, 0u, 0u, 0u}, xh[4] = {0u, 0u, 0u, 0u};
-                if (x_any) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(s_q8 + 64 + 4 * (lane & 7));
+                // hi / lo / XL planes: this lane's 16 bytes of each live in registers for the whole query (qp_*, set
+                // where the planes are built); XH, rarely non-zero, is read when needed
+                const uint32_t qh[4] = {qp_h.x, qp_h.y, qp_h.z, qp_h.w}, ql[4] = {qp_l.x, qp_l.y, qp_l.z, qp_l.w};
+                const uint32_t xl[4] = {qp_x.x, qp_x.y, qp_x.z, qp_x.w};
+                uint32_t xh[4] = {0u, 0u, 0u, 0u};
+                if (x_hi) {
                     const uint4 b = *reinterpret_cast<const uint4 *>(s_q8 + 96 + 4 * (lane & 7));
-                    xl[0] = a.x, xl[1] = a.y, xl[2] = a.z, xl[3] = a.w;
                     xh[0] = b.x, xh[1] = b.y, xh[2] = b.z, xh[3] = b.w;
                 }
                 for (int rb = 0;;) {
@@ -639,8 +642,9 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
                 float dq = 0.f;
                 if (active)
-                    dq = d128 ? l2_ref_order_oct128(g.vectors + (size_t)nbq * 128, q_reg, lane & 7)
-                              : l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                    dq = g.d == 128  ? l2_ref_order_oct_regs<16>(g.vectors + (size_t)nbq * 128, q_reg, lane & 7)
+                         : g.d == 96 ? l2_ref_order_oct_regs<12>(g.vectors + (size_t)nbq * 96, q_reg, lane & 7)
+                                     : l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
                 if (STAMPS) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t = walk_stamp();
