@@ -566,27 +566,25 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                             X[i] = oct_sum((int)(xlr - xhr));
                         }
                     }
-                    const int rel = lane - rb; // this link lane's row within the batch
-                    int mine = 0, minex = 0;
+                    // Every lane of group G = lane >> 3 holds the sums of rows rb + 8i + G (i = 0..3) in its own
+                    // registers: lane 8G + i evaluates the bound of row 8i + G from S[i], one ballot collects the
+                    // verdicts, and link lane L (row L - rb) reads bit 8 * ((L - rb) & 7) + ((L - rb) >> 3) of it --
+                    // no cross-lane traffic through the LDS crossbar (the eight ds_bpermute this replaces sat in
+                    // the dependent chain of every expansion).
+                    const int ii = lane & 7;
+                    int mine = S[0], minex = X[0];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int t = __shfl(S[i], (rel & 7) * 8, 64);
-                        if ((rel >> 3) == i)
-                            mine = t;
-                    }
-                    if (x_any) {
-#pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            const int t = __shfl(X[i], (rel & 7) * 8, 64);
-                            if ((rel >> 3) == i)
-                                minex = t;
-                        }
+                    for (int i = 1; i < 4; i++) {
+                        mine = ii == i ? S[i] : mine;
+                        minex = ii == i ? X[i] : minex;
                     }
                     const float m1 = fmaxf(0.f, sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
                     const float m2 = fmaf(m1, m1, fmaf((float)(minex + x_const), 0.9990234375f, pf_bonus));
                     const float m = fmaxf(0.f, sqrtf(m2) * 0.9990234375f - pf_slack) * g.q_step;
                     const float lb = m * m * 0.9990234375f;
-                    if (rel >= 0 && rel < 32 && lb > worst)
+                    const unsigned long long dropm = __ballot(ii < 4 && lb > worst);
+                    const int rel = lane - rb; // this link lane's row within the batch
+                    if (rel >= 0 && rel < 32 && ((dropm >> (8 * (rel & 7) + (rel >> 3))) & 1ull))
                         fresh = false;
                     rb += 32;
                     if (rb >= cnt)
