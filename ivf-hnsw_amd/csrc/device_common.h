@@ -66,6 +66,23 @@ __device__ __forceinline__ int oct_sum(int v)
     return v;
 }
 
+// Four values per lane, summed over each aligned group of 8 lanes as a reduce-scatter: lane 8G + ii returns the
+// group's sum of value 2 * bit2(ii) + bit0(ii) (lanes ii and ii ^ 2 hold the same one).  4 DPP adds + 6 selects.
+__device__ __forceinline__ int oct_sum4(const int (&S)[4], int lane)
+{
+    const bool b2 = (lane & 4) != 0, b0 = (lane & 1) != 0;
+    // partner 7 - i has the opposite bit 2: keep the pair {2 b2, 2 b2 + 1}, hand over the other
+    const int k0 = b2 ? S[2] : S[0], k1 = b2 ? S[3] : S[1];
+    const int h0 = b2 ? S[0] : S[2], h1 = b2 ? S[1] : S[3];
+    const int a0 = k0 + __builtin_amdgcn_update_dpp(0, h0, 0x141, 0xf, 0xf, true); // row_half_mirror
+    const int a1 = k1 + __builtin_amdgcn_update_dpp(0, h1, 0x141, 0xf, 0xf, true);
+    // partner i ^ 1: keep the one bit 0 names
+    const int k = b0 ? a1 : a0, h = b0 ? a0 : a1;
+    int c = k + __builtin_amdgcn_update_dpp(0, h, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+    c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1]: same value index there
+    return c;
+}
+
 // Exact reference distance (hnswalg.cpp:326-357) of one row evaluated by a QUAD of lanes: lane t of the quad
 // owns accumulators 2t and 2t+1 of the reference's eight, i.e. dims 8j+2t, 8j+2t+1 for j = 0..d/8-1 in
 // increasing order -- exactly the order each __m256 lane accumulates in.  All d/8 8-byte loads of a lane are

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1)
                 qp_sq += __shfl_xor(qp_sq, off, 64);
-            pf_slack = g.q_errc + 3.9e-6f * sqrtf(qp_sq);
+            pf_slack = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(g.q_errc + 3.9e-6f * sqrtf(qp_sq))));
             if (inline_rows) {
                 // The integer form of the filter.  q' = q_in + q_out: q_in is q' clamped to the byte range and
                 // rounded to 1/256 steps, Q = 256 * hi + lo (two byte planes in LDS); q_out is what the clamp cut
@@ -417,12 +417,15 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     s_xh += __shfl_xor(s_xh, off, 64);
                 }
                 // 128 * sum Q^2 / 65536 = 128 hh + hl + ll / 512  (< 2^31; the floor only lowers the bound)
-                q16_w = 128 * s_hh + s_hl + (s_ll >> 9);
+                // (wave-uniform after the butterflies: scalars, and scalar branches on x_any / x_hi below)
+                s_xl = __builtin_amdgcn_readfirstlane(s_xl);
+                s_xh = __builtin_amdgcn_readfirstlane(s_xh);
+                q16_w = __builtin_amdgcn_readfirstlane(128 * s_hh + s_hl + (s_ll >> 9));
                 x_any = (s_xl | s_xh) != 0;
                 x_hi = s_xh != 0;
                 x_const = 255 * s_xh;
-                pf_slack_q = 1.001f * sqrtf(dq_sq);
-                pf_bonus = 0.999f * bonus;
+                pf_slack_q = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(1.001f * sqrtf(dq_sq))));
+                pf_bonus = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(0.999f * bonus)));
                 __syncthreads();
                 qp_h = *reinterpret_cast<const uint4 *>(s_q8 + 4 * (lane & 7));
                 qp_l = *reinterpret_cast<const uint4 *>(s_q8 + 32 + 4 * (lane & 7));
@@ -553,38 +556,39 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                             lr = __builtin_amdgcn_udot4(ql[c], ws[c], lr, false);
                             rr = __builtin_amdgcn_udot4(ws[c], ws[c], rr, false);
                         }
-                        S[i] = oct_sum((int)(128u * rr - 256u * hr - lr)); // row rb + 8i + (lane >> 3)
+                        S[i] = (int)(128u * rr - 256u * hr - lr); // this lane's 16 bytes of row rb + 8i + (lane >> 3)
                         X[i] = 0;
-                        if (x_any) {
+                        if (x_any) { // wave-uniform (scalar): SIFT-like queries only ever leave the range downwards
                             uint32_t xlr = 0, xhr = 0;
 #pragma unroll
-                            for (int c = 0; c < 4; c++) {
+                            for (int c = 0; c < 4; c++)
                                 xlr = __builtin_amdgcn_udot4(xl[c], ws[c], xlr, false);
-                                if (x_hi) // wave-uniform; SIFT-like queries only ever leave the range downwards
+                            if (x_hi) {
+                                asm volatile("" ::); // a real (scalar) branch: hipcc otherwise computes and selects
+#pragma unroll
+                                for (int c = 0; c < 4; c++)
                                     xhr = __builtin_amdgcn_udot4(xh[c], ws[c], xhr, false);
                             }
-                            X[i] = oct_sum((int)(xlr - xhr));
+                            X[i] = (int)(xlr - xhr);
                         }
                     }
-                    // Every lane of group G = lane >> 3 holds the sums of rows rb + 8i + G (i = 0..3) in its own
-                    // registers: lane 8G + i evaluates the bound of row 8i + G from S[i], one ballot collects the
-                    // verdicts, and link lane L (row L - rb) reads bit 8 * ((L - rb) & 7) + ((L - rb) >> 3) of it --
-                    // no cross-lane traffic through the LDS crossbar (the eight ds_bpermute this replaces sat in
-                    // the dependent chain of every expansion).
-                    const int ii = lane & 7;
-                    int mine = S[0], minex = X[0];
-#pragma unroll
-                    for (int i = 1; i < 4; i++) {
-                        mine = ii == i ? S[i] : mine;
-                        minex = ii == i ? X[i] : minex;
-                    }
-                    const float m1 = fmaxf(0.f, sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
+                    // Group G = lane >> 3 holds rows rb + 8i + G (i = 0..3), 16 bytes per lane.  oct_sum4 leaves in
+                    // lane 8G + ii the complete sum of row i = 2 * bit2(ii) + bit0(ii) (a reduce-scatter: 4 DPP adds
+                    // instead of 12 for four full group sums); that lane evaluates the bound, one ballot collects
+                    // the verdicts of the lanes with bit1(ii) = 0, and link lane L (row L - rb = 8i + G) reads bit
+                    // 8G + 4 (i >> 1) + (i & 1) of it -- no cross-lane traffic through the LDS crossbar.
+                    const int mine = oct_sum4(S, lane);
+                    const int minex = x_any ? oct_sum4(X, lane) : 0;
+                    // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: the factors 1 - 2^-10 cover it
+                    const float m1 = fmaxf(
+                        0.f, __builtin_amdgcn_sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
                     const float m2 = fmaf(m1, m1, fmaf((float)(minex + x_const), 0.9990234375f, pf_bonus));
-                    const float m = fmaxf(0.f, sqrtf(m2) * 0.9990234375f - pf_slack) * g.q_step;
+                    const float m = fmaxf(0.f, __builtin_amdgcn_sqrtf(m2) * 0.9990234375f - pf_slack) * g.q_step;
                     const float lb = m * m * 0.9990234375f;
-                    const unsigned long long dropm = __ballot(ii < 4 && lb > worst);
+                    const unsigned long long dropm = __ballot((lane & 2) == 0 && lb > worst);
                     const int rel = lane - rb; // this link lane's row within the batch
-                    if (rel >= 0 && rel < 32 && ((dropm >> (8 * (rel & 7) + (rel >> 3))) & 1ull))
+                    const int ri = rel >> 3;
+                    if (rel >= 0 && rel < 32 && ((dropm >> (8 * (rel & 7) + 4 * (ri >> 1) + (ri & 1))) & 1ull))
                         fresh = false;
                     rb += 32;
                     if (rb >= cnt)
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     if (active)
                         S = byte_row_dist_half(g.qrows + (size_t)nbq * g.d, s_qp, g.d, lane & 1);
                     S += __shfl_xor(S, 1, 64);
-                    const float m = fmaxf(0.f, sqrtf(S) * 0.9990234375f - pf_slack) * g.q_step;
+                    const float m = fmaxf(0.f, __builtin_amdgcn_sqrtf(S) * 0.9990234375f - pf_slack) * g.q_step;
                     const float lb = m * m * 0.9990234375f;
                     const unsigned long long drop = __ballot(active && lb > worst);
                     const int rel = myrow - base;
