@@ -41,6 +41,14 @@ int ivfhnsw_gpu_abi_version(void);
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out);
 int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h);
 
+/* A second search context on the SAME device tables: own stream, own per-batch workspace, nothing copied.
+ * Batches submitted to the parent and to its views run concurrently (the walk is ALU-bound, the scan HBM-bound:
+ * two batches in flight overlap them and fill each other's tails).  The reference's nearest notion is one
+ * IndexIVF_HNSW searched from several OpenMP threads, which its member scratch forbids (SURVEY 8b "Threading").
+ * The parent must outlive its views and must not upload again while they exist; uploads on a view fail
+ * (IVFHNSW_ERR_STATE).  Destroy with ivfhnsw_gpu_destroy. */
+int ivfhnsw_gpu_create_view(ivfhnsw_gpu *parent, ivfhnsw_gpu **out);
+
 /* Optional: run on a caller-owned hipStream_t (passed as void*) instead of the handle's own stream. */
 int ivfhnsw_gpu_set_stream(ivfhnsw_gpu *h, void *hip_stream);
 /* Block until everything queued on the handle's stream has finished.  Also reports (as

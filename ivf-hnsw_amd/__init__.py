@@ -19,7 +19,7 @@ STAGES = ("opq", "coarse", "lut", "plan", "scan", "select")
 
 # every symbol include/ivfhnsw_hip.h declares
 ABI_SYMBOLS = (
-    "ivfhnsw_gpu_last_error", "ivfhnsw_gpu_abi_version", "ivfhnsw_gpu_create", "ivfhnsw_gpu_destroy",
+    "ivfhnsw_gpu_last_error", "ivfhnsw_gpu_abi_version", "ivfhnsw_gpu_create", "ivfhnsw_gpu_create_view", "ivfhnsw_gpu_destroy",
     "ivfhnsw_gpu_set_stream", "ivfhnsw_gpu_sync", "ivfhnsw_gpu_upload_ivf", "ivfhnsw_gpu_upload_ivf_synthetic",
     "ivfhnsw_gpu_upload_grouping", "ivfhnsw_gpu_upload_quantizer", "ivfhnsw_gpu_search", "ivfhnsw_gpu_search_dev",
     "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
@@ -67,6 +67,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.ivfhnsw_gpu_last_error.restype = C.c_char_p
         L.ivfhnsw_gpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.ivfhnsw_gpu_create_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.ivfhnsw_gpu_destroy.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_sync.argtypes = [C.c_void_p]
@@ -131,6 +132,16 @@ class GpuIndex:
         self._h = C.c_void_p()
         _check(lib().ivfhnsw_gpu_create(device, C.byref(self._h)))
         self.d = self.nc = self.code_size = 0
+
+    def view(self):
+        """A second search context on this index's device tables (own stream and workspace; nothing copied).
+        Keep this object alive, and do not upload to it, while the view is in use."""
+        v = GpuIndex.__new__(GpuIndex)
+        v._h = C.c_void_p()
+        _check(lib().ivfhnsw_gpu_create_view(self._h, C.byref(v._h)))
+        v.d, v.nc, v.code_size = self.d, self.nc, self.code_size
+        v._parent = self
+        return v
 
     def close(self):
         if self._h:

@@ -76,6 +76,7 @@ struct ivfhnsw_gpu {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool is_view = false; // ivfhnsw_gpu_create_view: tables belong to the parent, workspace and stream are its own
 
     // index tables
     DevBuf goff, loff, cnorm, pqc, ntab, opq_at, codes, ncodes, ids;
@@ -286,7 +287,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 5; }
+int ivfhnsw_gpu_abi_version(void) { return 6; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
@@ -345,6 +346,33 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     return IVFHNSW_OK;
 }
 
+int ivfhnsw_gpu_create_view(ivfhnsw_gpu *parent, ivfhnsw_gpu **out)
+{
+    if (!out)
+        return fail(IVFHNSW_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int rc = bind(parent);
+    if (rc)
+        return rc;
+    if (parent->is_view)
+        return fail(IVFHNSW_ERR_INVALID, "a view of a view: create it from the handle that holds the tables");
+    // the parent's uploads (and the neighbour-row build) run on its stream: finished before anyone reads them
+    HIP_TRY(hipStreamSynchronize(parent->stream));
+    ivfhnsw_gpu *h = nullptr;
+    if ((rc = ivfhnsw_gpu_create(parent->device, &h)))
+        return rc;
+    h->is_view = true;
+    h->t = parent->t;
+    h->has_ivf = parent->has_ivf;
+    h->n_local = parent->n_local;
+    h->g = parent->g;
+    h->has_group = parent->has_group;
+    h->gr = parent->gr;
+    h->has_graph = parent->has_graph;
+    *out = h;
+    return IVFHNSW_OK;
+}
+
 int ivfhnsw_gpu_set_stream(ivfhnsw_gpu *h, void *hip_stream)
 {
     int rc = bind(h);
@@ -369,6 +397,8 @@ int ivfhnsw_gpu_sync(ivfhnsw_gpu *h)
 
 int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
 {
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -396,6 +426,8 @@ int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
 
 int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, uint64_t seed)
 {
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -429,6 +461,8 @@ int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, 
 int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alphas, const uint32_t *nn_centroid_idxs,
                                 const uint32_t *subgroup_sizes, const float *inter_centroid_dists)
 {
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -553,6 +587,8 @@ static int build_neighbour_rows(ivfhnsw_gpu *h)
 int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
                                  const uint8_t *link_counts, const uint32_t *links, const float *vectors)
 {
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -702,6 +738,8 @@ int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k
 int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, const float *pq_centroids,
                                  const float *norm_table, const float *opq_A)
 {
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
     if (rc)
         return rc;
