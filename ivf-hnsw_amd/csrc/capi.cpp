@@ -674,7 +674,13 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
                                d_coarse_dists, h->w_visited.as<uint32_t>(), words, nwaves,
                                h->w_status.as<uint32_t>(), h->w_status.as<uint32_t>() + 1));
     } else {
-        const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
+        // IVFHNSW_WALK_SLOTS caps the wavefronts the walk is launched with (experiments on the rounds a batch takes)
+        static const size_t slot_cap = [] {
+            const char *e = getenv("IVFHNSW_WALK_SLOTS");
+            const long v = e ? atol(e) : 0;
+            return v > 0 ? (size_t)v : (size_t)-1;
+        }();
+        const int nslots = (int)std::min<size_t>(std::min<size_t>(nq, slot_cap), (size_t)coarse_slots_for((int)efSearch));
         if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
             return rc;
         HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,

@@ -344,10 +344,14 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         __syncthreads(); // also orders the bitmap reset before the atomics below
         // d = 128 (SIFT) and 96 (DEEP): the lane's share of the query for the 8-lanes-per-row distance stays in
         // registers (one LDS round trip less in every expansion's dependent chain)
-        float q_reg[16];
+        // (builds for more than 4 waves per SIMD have no registers to spare for it)
+        constexpr bool QREG = MINW <= 4;
+        float q_reg[QREG ? 16 : 1];
+        if constexpr (QREG) {
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            q_reg[i] = (g.d == 128 || g.d == 96) && 8 * i < g.d ? s_q[8 * i + (lane & 7)] : 0.f;
+            for (int i = 0; i < 16; i++)
+                q_reg[i] = (g.d == 128 || g.d == 96) && 8 * i < g.d ? s_q[8 * i + (lane & 7)] : 0.f;
+        }
         // slack of the rejection test in byte-row units: quantisation error of the worst row, plus what the
         // rounding of s_qp can move a distance by (<= 2^-22 ||q'||; 2^-18 leaves a factor 16)
         float pf_slack = 0.f, pf_slack_q = 0.f, pf_bonus = 0.f;
@@ -643,10 +647,14 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 const int src = active ? nth_set_bit(mask, r) : 0;
                 const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
                 float dq = 0.f;
-                if (active)
-                    dq = g.d == 128  ? l2_ref_order_oct_regs<16>(g.vectors + (size_t)nbq * 128, q_reg, lane & 7)
-                         : g.d == 96 ? l2_ref_order_oct_regs<12>(g.vectors + (size_t)nbq * 96, q_reg, lane & 7)
-                                     : l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                if (active) {
+                    if constexpr (QREG)
+                        dq = g.d == 128  ? l2_ref_order_oct_regs<16>(g.vectors + (size_t)nbq * 128, q_reg, lane & 7)
+                             : g.d == 96 ? l2_ref_order_oct_regs<12>(g.vectors + (size_t)nbq * 96, q_reg, lane & 7)
+                                         : l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                    else
+                        dq = l2_ref_order_oct(g.vectors + (size_t)nbq * g.d, s_q, g.d, lane & 7);
+                }
                 if (STAMPS) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned long long t = walk_stamp();
@@ -804,7 +812,15 @@ hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbr
 int coarse_slots_for(int ef)
 {
     const int nch = (ef + 63) / 64;
-    const int waves_per_simd = nch <= 4 ? 8 : (nch <= 8 ? 4 : 3); // upper bound; extra blocks just find the queue empty
+    // Exactly the wavefronts that can be resident (256 CUs x 4 SIMDs x the waves per SIMD the kernel is built for;
+    // its registers allow no more): blocks beyond that only start when a slot frees up, find the queue empty and
+    // cost their prologue -- 1.205 vs 1.189 ms per 10 k queries with 8192 instead of 4096 blocks.
+    static const int occ = [] {
+        const char *e = getenv("IVFHNSW_WALK_OCC");
+        const int v = e ? atoi(e) : 4;
+        return (v == 5 || v == 6) ? v : 4;
+    }();
+    const int waves_per_simd = nch <= 4 ? occ : (nch <= 8 ? 4 : 3);
     return 256 * 4 * waves_per_simd;
 }
 
