@@ -598,12 +598,22 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     if (d % 16)
         return fail(IVFHNSW_ERR_INVALID, "d %zu: the reference distance ignores dims beyond a multiple of 16 "
                                          "(hnswalg.cpp:330); only multiples of 16 are supported here", d);
+    // link lists without repeated ids (every graph the reference builds): the walk may then enter a pass's
+    // survivors into the visited set late (kernels_hnsw.hip, filter_first)
+    bool unique = true;
+    uint32_t tmp[256];
     for (size_t i = 0; i < n; i++) {
         if (link_counts[i] > maxM)
             return fail(IVFHNSW_ERR_INVALID, "node %zu has %u links > maxM %zu", i, link_counts[i], maxM);
         for (size_t j = 0; j < link_counts[i]; j++)
             if (links[i * maxM + j] >= n)
                 return fail(IVFHNSW_ERR_INVALID, "node %zu link %zu out of range", i, j);
+        if (unique && link_counts[i] > 1) {
+            const size_t c = link_counts[i];
+            std::copy(links + i * maxM, links + i * maxM + c, tmp);
+            std::sort(tmp, tmp + c);
+            unique = std::adjacent_find(tmp, tmp + c) == tmp + c;
+        }
     }
     if ((rc = upload(h->q_counts, link_counts, n)))
         return rc;
@@ -624,6 +634,18 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
             return (e && atoi(e) == 0) ? 0 : 1;
         }();
         h->gr.merge_admissions = merge;
+    }
+    {
+        // IVFHNSW_WALK_LATE_VISIT: 1 always, 0 never, unset = where it pays -- graphs whose ids need more than 8 tag
+        // bits (beyond 255 * 896 nodes), where the visited set of a query would otherwise run 40 % full and
+        // overflow into global atomics (1.60 -> 1.50 ms per 10 k queries at 993 127 nodes; at 2^17 nodes the extra
+        // LDS pass costs 1 %: 1.19 -> 1.205 ms)
+        static const int late_knob = [] {
+            const char *e = getenv("IVFHNSW_WALK_LATE_VISIT");
+            return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        }();
+        const bool late = late_knob < 0 ? n > 255u * 896u : late_knob == 1;
+        h->gr.links_unique = (unique && late) ? 1 : 0;
     }
     h->gr.qrows = nullptr;
     h->gr.nbrows = nullptr;

@@ -72,6 +72,7 @@ struct GraphTables {
     const uint8_t *nbrows;
     int nb_rows;
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
+    int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
 };
 
 // y[q][i] = fmaf chain over k of A[i][k] * x[q][k]  (IndexIVF_HNSW.cpp:240)

@@ -229,6 +229,26 @@ __device__ __forceinline__ bool visit_test_and_set(uint32_t id, unsigned long lo
     return !(atomicOr(&bm[id >> 5], bit) & bit);
 }
 
+// Read-only membership test of the LDS set (TAGW != 0).  An id whose bucket is full may live in the wave's bitmap:
+// read through a returning atomic, which sees the atomicOr of earlier insertions (a plain load could hit a stale
+// L1 line).
+template <int TAGW, int NB>
+__device__ __forceinline__ bool visit_lookup(uint32_t id, const unsigned long long *vt, uint32_t *bm)
+{
+    static_assert(TAGW != 0, "LDS set only");
+    constexpr unsigned long long kOnes = VisFields<TAGW>::ones();
+    constexpr unsigned long long kHighs = kOnes << (TAGW - 1);
+    const uint32_t b = id % (uint32_t)NB;
+    const unsigned long long tag = (unsigned long long)((id / (uint32_t)NB) + 1);
+    const unsigned long long old = vt[b];
+    const unsigned long long x = old ^ (tag * kOnes);
+    if ((x - kOnes) & ~x & kHighs)
+        return true;
+    if ((old - kOnes) & ~old & kHighs)
+        return false; // a free field: everything that hashed here so far is in the bucket
+    return (atomicOr(&bm[id >> 5], 0u) >> (id & 31)) & 1u;
+}
+
 // sum over half of a byte row (16-byte chunks h, h+2, ...) of (q'[i] - byte[i])^2; the pair of lanes adds up
 __device__ __forceinline__ float byte_row_dist_half(const uint8_t *row, const float *sqp, int d, int h)
 {
@@ -277,7 +297,8 @@ __device__ __forceinline__ unsigned long long walk_stamp()
     return t;
 }
 
-// FMODE: the exact rejection filter -- 0 off, 1 gather from GraphTables::qrows, 2 neighbour rows (nbrows)
+// FMODE: the exact rejection filter -- 0 off, 1 gather from GraphTables::qrows, 2 neighbour rows (nbrows),
+// 3 neighbour rows with the survivors entered into the visited set late (see filter_first)
 template <int NCH, int MINW, int TAGW, int FMODE, bool STAMPS = false>
 __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, const float *__restrict__ xq, int nq, int nprobe,
                                                        int ef, uint32_t *__restrict__ coarse_ids,
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     const int lane = threadIdx.x;
     const bool merge_on = g.merge_admissions != 0;
     constexpr bool prefilter = FMODE != 0;
-    constexpr bool inline_rows = FMODE == 2;
+    constexpr bool inline_rows = FMODE >= 2;
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
     bool bitmap_dirty = true; // the bitmap must be wiped before its first use and after any query that used it
 
@@ -454,6 +475,9 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             __syncthreads();
         }
         bool used_bitmap = false;
+        // survivors of the last pass, entered into the visited set at the top of the next expansion
+        bool pend = false, pend_any = false;
+        uint32_t pend_id = 0;
         if (STAMPS) {
             const unsigned long long t = walk_stamp();
             st_acc[4] += t - st_t;
@@ -530,12 +554,38 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 for (int i = 0; i < 4; i++)
                     nw[i] = nbr[i * 64];
             }
-            bool fresh = false;
-            if (lane < cnt)
-                fresh = visit_test_and_set<TAGW, NB>(nb, vt, bm, used_bitmap);
+            // With the neighbour-row filter on (and the LDS set), only the rows the filter lets through are ENTERED
+            // into the visited set: a row it rejects has dist >= bound > max(topResults), the maximum never grows
+            // and the bound is a function of (row, query) alone, so the row is rejected again whenever it comes
+            // back -- marking it visited (hnswalg.cpp:80-82) changes nothing.  The set then holds ~5 ids per
+            // expansion instead of ~27 (no bucket overflows, hardly any compare-and-swap retries), the membership
+            // test is a plain LDS read, and the insertions of a pass's survivors wait until the NEXT expansion's
+            // loads are in flight (just above the test, which must see them) -- off the dependent chain.  Needs
+            // link lists without repeated ids (checked at upload): a repeated survivor would be entered twice.
+            constexpr bool LATE = FMODE == 3 && LDSVIS; // the launcher picks it only for GraphTables::links_unique
+            const bool filter_first = LATE && filter_now;
+            bool fresh = false, seen = false;
+            if constexpr (LATE) {
+                if (pend_any) {
+                    if (pend)
+                        (void)visit_test_and_set<TAGW, NB>(pend_id, vt, bm, used_bitmap);
+                    pend_any = false;
+                }
+                if (lane < cnt) {
+                    if (filter_first)
+                        seen = visit_lookup<TAGW, NB>(nb, vt, bm);
+                    else
+                        fresh = visit_test_and_set<TAGW, NB>(nb, vt, bm, used_bitmap);
+                }
+            } else {
+                if (lane < cnt)
+                    fresh = visit_test_and_set<TAGW, NB>(nb, vt, bm, used_bitmap);
+            }
             unsigned long long mask = __ballot(fresh);
             int nfresh = __popcll(mask);
             if (filter_now && inline_rows) {
+                if (filter_first)
+                    fresh = lane < cnt && !seen;
                 // (see the gather form below for the bound)  Link lane L is row L of the node's block.
                 const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
                 // hi / lo / XL planes: this lane's 16 bytes of each live in registers for the whole query (qp_*, set
@@ -605,6 +655,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 }
                 mask = __ballot(fresh);
                 nfresh = __popcll(mask);
+                if (filter_first) {
+                    pend = fresh;
+                    pend_id = nb;
+                    pend_any = nfresh > 0;
+                }
             } else if (filter_now && nfresh > 0) {
                 // ---- exact rejection filter.  Once the set is full a row is admitted only if its distance is
                 // below the current maximum (hnswalg.cpp:93), and the maximum never grows.  A lower bound of
@@ -875,13 +930,15 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
                        (size_t)(kTailCap + ((ef <= 256 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) *
                            sizeof(unsigned long long) +
                        (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
-    const int fmode = g.nbrows ? 2 : g.qrows ? 1 : 0;
+    const int fmode = g.nbrows ? (g.links_unique && tagw ? 3 : 2) : g.qrows ? 1 : 0;
 #define IVFHNSW_WALK_F(N, W, T, F)                                                                                    \
     hipLaunchKernelGGL((hnsw_walk_kernel<N, W, T, F>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,         \
                        coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
 #define IVFHNSW_WALK_T(N, W, T)          \
     do {                                 \
-        if (fmode == 2)                  \
+        if (fmode == 3)                  \
+            IVFHNSW_WALK_F(N, W, T, 3);  \
+        else if (fmode == 2)             \
             IVFHNSW_WALK_F(N, W, T, 2);  \
         else if (fmode == 1)             \
             IVFHNSW_WALK_F(N, 4, T, 1);  \

@@ -8,6 +8,10 @@ data the bytes represent exactly (zero quantisation slack, exact ties at the bou
 128-byte record (zero padded), degrees beyond one 32-row batch, and dimensions that select the gather form
 (d > 128) or no filter at all (d > 2048, constant tables).
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -93,6 +97,27 @@ def test_degree_beyond_one_row_batch(gpu):
     _walk_both(gpu(), graph, _stress_queries(rng, cents, 16), 32, 64)
 
 
+def test_link_lists_with_repeated_ids(gpu):
+    """The same neighbour twice in a link list (never in a graph the reference built, but an uploaded one may): the
+    second occurrence counts as visited (hnswalg.cpp:80-82), also where the walk enters the pass's survivors into
+    the visited set only after their rows were requested."""
+    rng = np.random.default_rng(115)
+    cents = synth.sift_like(rng, 4096, 128)
+    built = orc.Hnsw.build(cents, M=16, efConstruction=60)
+    counts = built.counts.copy()
+    links = built.links.copy().reshape(len(counts), -1)
+    maxM = links.shape[1]
+    for i in range(len(counts)):
+        c = int(counts[i])
+        extra = min(maxM - c, 1 + i % 3)
+        if c and extra > 0:
+            links[i, c:c + extra] = links[i, rng.integers(0, c, extra)]   # repeats of links it already has
+            counts[i] = c + extra
+    graph = orc.Hnsw.from_arrays(counts, links, built.vectors, 16, built.enterpoint)
+    assert (counts > built.counts).mean() > 0.5
+    _walk_both(gpu(), graph, _stress_queries(rng, cents, 16), 32, 80)
+
+
 @pytest.mark.parametrize("d", [144, 256])
 def test_gather_form_beyond_128_dims(gpu, d):
     rng = np.random.default_rng(106 + d)
@@ -110,3 +135,35 @@ def test_tables_without_a_filter(gpu):
     const = np.full((64, 32), 7.0, np.float32)
     graph = orc.Hnsw.build(const, M=4, efConstruction=10)
     _walk_both(gpu(), graph, synth.sift_like(rng, 6, 32), 4, 8)
+
+
+LATE_CHILD = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import __graft_entry__ as ge
+import test_gpu_walk_filter as m
+pkg = ge.load_pkg()
+made = []
+def gpu():
+    made.append(pkg.GpuIndex(0))
+    return made[-1]
+for ef, k in ((16, 16), (80, 32), (200, 64)):
+    m.test_queries_outside_the_byte_range(gpu, ef, k)
+m.test_signed_unit_vectors_d96(gpu)
+m.test_rows_the_bytes_represent_exactly(gpu)
+m.test_degree_beyond_one_row_batch(gpu)
+m.test_link_lists_with_repeated_ids(gpu)
+print("LATE OK", len(made))
+'''
+
+
+def test_late_visit_form_in_a_child_process():
+    """The form the walk takes on graphs beyond 228 k nodes (survivors of the filter entered into the visited set at
+    the next expansion; IVFHNSW_WALK_LATE_VISIT=1 forces it, read once per process): the cases above again.  Link
+    lists with repeated ids must fall back to the early test by themselves."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, IVFHNSW_WALK_LATE_VISIT="1")
+    r = subprocess.run([sys.executable, "-c", LATE_CHILD % dict(root=root)], capture_output=True, text=True, env=e,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "LATE OK" in r.stdout
