@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/probe
 rm -rf "$O"; mkdir -p "$O"
-B="python3 $PWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline"
+B="python3 $PWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --in-flight 1 $BENCH_ARGS"
 cd /tmp
 i=0
 for set in "$@"; do
@@ -22,6 +22,6 @@ for f in sorted(glob.glob(sys.argv[1]+'/p*/**/*counter_collection.csv',recursive
         k=(r['Kernel_Name'].split('(')[0][:40],r['Counter_Name'])
         acc[k][0]+=1; acc[k][1]+=float(r['Counter_Value'])
     for k,v in sorted(acc.items()):
-        if 'walk' in k[0] or 'scan' in k[0]:
+        if 'walk' in k[0] or 'scan' in k[0] or 'plan' in k[0]:
             print(k[0],k[1],v[0],v[1]/v[0])
 PY
