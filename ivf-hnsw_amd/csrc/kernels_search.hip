@@ -420,8 +420,19 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                             while (p >= s_lpos[s + 1])
                                 s++;
                         } else {
-                            // first s with s_lpos[s+1] > p, searched in (s, cn)
+                            // first s with s_lpos[s+1] > p, searched in (s, cn).  Inverted lists are about as long
+                            // as the block's stride (1024 positions), so the segment is usually the next one or the
+                            // one after: two steps forward before the binary search (which sub-group plans need).
                             uint32_t a = s, b = cn - 1;
+                            if (a < b && s_lpos[a + 1] <= p) {
+                                a++;
+                                if (a < b && s_lpos[a + 1] <= p)
+                                    a++;
+                                else
+                                    b = a;
+                            } else {
+                                b = a;
+                            }
                             while (a < b) {
                                 const uint32_t mid = (a + b) >> 1;
                                 if (s_lpos[mid + 1] > p)
