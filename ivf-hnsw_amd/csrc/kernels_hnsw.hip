@@ -764,12 +764,17 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     if (is_cand)
                         mb[set_below + cand_below] = Kc;
                     __syncthreads();
-                    const bool clean = key_dist_bits(mb[ef - 1]) != key_dist_bits(mb[ef]);
+                    // boundary and merged entries read together: one LDS round trip, the verdict picks afterwards
+                    const unsigned long long b_lo = mb[ef - 1], b_hi = mb[ef];
+                    unsigned long long merged[NCH];
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++)
+                        merged[cc] = cc * 64 + lane < ef ? mb[cc * 64 + lane] : R.r[cc];
+                    const bool clean = key_dist_bits(b_lo) != key_dist_bits(b_hi);
                     if (clean) {
 #pragma unroll
                         for (int cc = 0; cc < NCH; cc++)
-                            if (cc * 64 + lane < ef)
-                                R.r[cc] = mb[cc * 64 + lane];
+                            R.r[cc] = merged[cc];
                         if (STAMPS)
                             st_acc[8] += (unsigned long long)__popcll(__ballot(is_cand && set_below + cand_below < ef));
                         cand = 0;
