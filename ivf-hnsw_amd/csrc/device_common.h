@@ -51,6 +51,27 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long mask, int r)
     return pos;
 }
 
+// The next eight set bits of a WAVE-UNIFORM mask, consumed from it: lane group g = lane >> 3 gets the position of
+// the g-th of them (0 where the mask ran out).  All on the scalar unit (s_ff1 / s_lshl / s_or per bit) plus one
+// 64-bit shift per lane, where nth_set_bit costs ~54 vector instructions for a per-lane rank.
+__device__ __forceinline__ int take8_set_bits(unsigned long long &m, int lane)
+{
+    // (a sentinel at bit 63 keeps the count-trailing-zeros defined: an exhausted mask yields position 63, which
+    // only lanes without a row ever see)
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t p = (uint32_t)__builtin_ctzll(m | (1ull << 63));
+        if (j < 4)
+            lo |= p << (8 * j);
+        else
+            hi |= p << (8 * (j - 4));
+        m &= ~(1ull << p);
+    }
+    const uint32_t w = (lane & 32) ? hi : lo;
+    return (int)((w >> (8 * ((lane >> 3) & 3))) & 0xffu);
+}
+
 // broadcast lane k of each quad to the whole quad (DPP quad_perm, no LDS)
 template <int K> __device__ __forceinline__ float quad_bcast(float v)
 {

@@ -696,10 +696,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
 
             // ---- distances, 8 rows per pass (eight lanes per row), then admissions in link order
+            unsigned long long rest = mask; // link lanes not yet dealt to a pass
             for (int base = 0; base < nfresh && ntail >= 0; base += 8) {
                 const int r = base + (lane >> 3);
                 const bool active = r < nfresh;
-                const int src = active ? nth_set_bit(mask, r) : 0;
+                const int src = take8_set_bits(rest, lane); // the r-th fresh link lane (0 beyond the last)
                 const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
                 float dq = 0.f;
                 if (active) {
