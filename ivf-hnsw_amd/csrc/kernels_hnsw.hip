@@ -737,10 +737,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     // leaves the registers untouched and takes the sequential path.
                     const bool is_cand = (cand >> lane) & 1ull;
                     const unsigned long long Kc = mk_key(dq, nbq);
-                    int up[NCH]; // candidates below this lane's set entries
+                    int dn[NCH]; // candidates ABOVE this lane's set entries (an add-with-carry per compare)
 #pragma unroll
                     for (int cc = 0; cc < NCH; cc++)
-                        up[cc] = 0;
+                        dn[cc] = 0;
+                    const int ncand = __popcll(cand);
                     int cand_below = 0, set_below = 0;
                     for (unsigned long long cm = cand; cm; cm &= cm - 1) {
                         const int b = __ffsll((long long)cm) - 1;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                         for (int cc = 0; cc < NCH; cc++) {
                             const bool lt = cc * 64 + lane < ef && (R.r[cc] & ~1ull) < Kj;
                             below += __popcll(__ballot(lt));
-                            up[cc] += lt ? 0 : 1;
+                            dn[cc] += lt ? 1 : 0;
                         }
                         cand_below += Kj < Kc ? 1 : 0;
                         set_below = lane == b ? below : set_below;
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 #pragma unroll
                     for (int cc = 0; cc < NCH; cc++)
                         if (cc * 64 + lane < ef)
-                            mb[cc * 64 + lane + up[cc]] = R.r[cc];
+                            mb[cc * 64 + lane + (ncand - dn[cc])] = R.r[cc];
                     if (is_cand)
                         mb[set_below + cand_below] = Kc;
                     __syncthreads();
