@@ -39,6 +39,9 @@ WORKLOADS = {
     # Grouping + Pruning + OPQ at the reference's preset (examples/run_sift1b_grouping_OPQ.sh:7-53): nsubc 64
     "grouping-100M-pq16-nc131072-nsubc64-opq-pruning": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
     "grouping-10M-pq16-nc16384-nsubc64-opq-pruning": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
+    # ... and at the reference's full size (BASELINE.json configs[3]) on ONE GPU; --no-cpu-baseline as for the 1B
+    # shapes below
+    "grouping-1B-pq16-nc993127-nsubc64-opq-pruning": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
     # The 1B shapes of BASELINE.json configs[2] and [4] on ONE GPU (21 GB of lists; run with --no-cpu-baseline:
     # the host copy of a 1B corpus is not built).  Parameters: examples/run_sift1b.sh:37-43 (the two paper
     # points) and examples/run_deep1b_OPQ.sh.
@@ -131,11 +134,7 @@ def main():
         gt = synth.make_grouping_tables(args.seed + 3, tb, 64, device=dev)
         opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
         # the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800)
-        from oracle import orc as _orc
-        rg = _orc.Hnsw.from_arrays(counts, links, tb["centroids"], 16, 0)
-        rg.rotate(opq_A)
-        vectors = rg.vectors.copy()
-        rg.free()
+        vectors = synth.rotated_vectors(tb["centroids"], opq_A)
     g = pkg.GpuIndex(local_rank)
     code_seed = args.seed + 7
     t0 = time.time()

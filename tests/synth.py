@@ -335,6 +335,17 @@ def make_grouping_tables(seed, tb, nsubc, device=None):
     return dict(nsubc=nsubc, nn_centroid_idxs=nn, alphas=alphas, subgroup_sizes=sg, inter_centroid_dists=icd)
 
 
+def rotated_vectors(vectors, A):
+    """The quantizer's vectors after rotate_quantizer (IndexIVF_HNSW.cpp:789-800), in the reference's float order
+    (through the oracle: synthetic-data preparation for the Grouping workloads, never part of what is measured)."""
+    n = len(vectors)
+    g = orc.Hnsw.from_arrays(np.zeros(n, np.uint8), np.zeros((n, 1), np.uint32), vectors, 1)
+    g.rotate(A)
+    out = g.vectors.copy()
+    g.free()
+    return out
+
+
 def make_encode_case(seed, nc, d, M, opq, n, hnsw_M=8, kind="sift"):
     """Inputs of an add_batch parity case (construction side): centroids, their reference-identical graph, code
     books, optional OPQ matrix, base vectors, and the oracle index that encodes them."""
