@@ -61,6 +61,14 @@ __device__ __forceinline__ unsigned long long lane_below_u64(unsigned long long 
     return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 
+// lanes of register cc that hold entries below index n (wave-uniform, scalar unit): ANDed with a ballot it replaces
+// a per-lane range compare inside the ballot's operand, which hipcc materialises through a select and a compare
+__device__ __forceinline__ unsigned long long lanes_below(int n, int cc)
+{
+    const int r = n - cc * 64;
+    return r >= 64 ? ~0ull : (r > 0 ? (1ull << r) - 1ull : 0ull);
+}
+
 template <int NCH> struct RSet {
     unsigned long long r[NCH]; // entry i: lane i & 63, register i >> 6
 
@@ -97,7 +105,7 @@ template <int NCH> struct RSet {
         int first = -1;
 #pragma unroll
         for (int cc = 0; cc < NCH; cc++) {
-            const unsigned long long m = __ballot(cc * 64 + lane < n && !(r[cc] & 1ull));
+            const unsigned long long m = __ballot(!(r[cc] & 1ull)) & lanes_below(n, cc);
             if (m && first < 0)
                 first = cc * 64 + (__ffsll((long long)m) - 1);
         }
@@ -639,7 +647,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     const float m2 = fmaf(m1, m1, fmaf((float)(minex + x_const), 0.9990234375f, pf_bonus));
                     const float m = fmaxf(0.f, __builtin_amdgcn_sqrtf(m2) * 0.9990234375f - pf_slack) * g.q_step;
                     const float lb = m * m * 0.9990234375f;
-                    const unsigned long long dropm = __ballot((lane & 2) == 0 && lb > worst);
+                    const unsigned long long dropm = __ballot(lb > worst) & 0x3333333333333333ull; // lanes with bit 1 clear
                     const int rel = lane - rb; // this link lane's row within the batch
                     const int ri = rel >> 3;
                     if (rel >= 0 && rel < 32 && ((dropm >> (8 * (rel & 7) + 4 * (ri >> 1) + (ri & 1))) & 1ull))
@@ -722,7 +730,9 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 // against the current maximum fails against every later one too.
                 unsigned long long topk = R.get(n - 1); // the set's last entry, carried through the loop
                 const float top0 = __uint_as_float(key_dist_bits(topk));
-                unsigned long long cand = __ballot(active && (lane & 7) == 0 && (n < ef || top0 > dq));
+                // (first lane of each row's group, rows that exist: constant and scalar masks instead of per-lane tests)
+                unsigned long long cand = (n < ef ? ~0ull : __ballot(top0 > dq)) & 0x0101010101010101ull &
+                                          lanes_below(8 * (nfresh - base), 0);
                 if (STAMPS) {
                     st_acc[6] += (unsigned long long)__popcll(__ballot(active && (lane & 7) == 0));
                     st_acc[7] += (unsigned long long)__popcll(cand);
@@ -751,8 +761,10 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                         int below = 0;
 #pragma unroll
                         for (int cc = 0; cc < NCH; cc++) {
-                            const bool lt = cc * 64 + lane < ef && (R.r[cc] & ~1ull) < Kj;
-                            below += __popcll(__ballot(lt));
+                            // (entries at and beyond ef are left-overs: their dn is never used, the mask keeps
+                            // them out of the count)
+                            const bool lt = (R.r[cc] & ~1ull) < Kj;
+                            below += __popcll(__ballot(lt) & lanes_below(ef, cc));
                             dn[cc] += lt ? 1 : 0;
                         }
                         cand_below += Kj < Kc ? 1 : 0;
