@@ -167,6 +167,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not warm-up: the first steps size the per-batch workspace (hipMalloc) and bring the clocks up; they run
+    # whatever --warmup says, so that a short run (--warmup 0) does not time allocations
+    for _ in range(3):
+        step()
+    barrier()
     for _ in range(args.warmup):
         step()
     barrier()
