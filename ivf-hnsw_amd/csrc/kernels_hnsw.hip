@@ -1017,6 +1017,8 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
         IVFHNSW_WALK_N(1);
     } else if (nch <= 2) {
         IVFHNSW_WALK_N(2);
+    } else if (nch == 3) { // efSearch 129..192 (the reference's DEEP1B presets use 130)
+        IVFHNSW_WALK_N(3);
     } else if (nch <= 4) {
         IVFHNSW_WALK_N(4);
     } else if (nch <= 8) {
