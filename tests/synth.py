@@ -34,6 +34,16 @@ def hash_bytes(seed, first_byte, nbytes):
     """Bytes [first_byte, first_byte+nbytes) of the device's synthetic stream (kernels_search.hip fill_bytes)."""
     if nbytes == 0:
         return np.zeros(0, np.uint8)
+    if nbytes > (1 << 30):  # 1B-vector corpora: in pieces, so that the temporaries stay small
+        out = np.empty(nbytes, np.uint8)
+        step = 1 << 29
+        for a in range(0, nbytes, step):
+            n = min(step, nbytes - a)
+            out[a:a + n] = hash_bytes(seed, first_byte + a, n)
+            if (a // step) % 8 == 7:   # minutes of work: keep a watcher of stderr informed
+                print("[synth] host copy of the synthetic stream: %.0f / %.0f GiB" % ((a + n) / 2 ** 30, nbytes / 2 ** 30),
+                      file=sys.stderr, flush=True)
+        return out
     w0 = first_byte // 8
     w1 = (first_byte + nbytes + 7) // 8
     with np.errstate(over="ignore"):
