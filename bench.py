@@ -40,11 +40,11 @@ WORKLOADS = {
     "grouping-100M-pq16-nc131072-nsubc64-opq-pruning": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
     "grouping-10M-pq16-nc16384-nsubc64-opq-pruning": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
     # ... and at the reference's full size (BASELINE.json configs[3]) on ONE GPU; --no-cpu-baseline as for the 1B
-    # shapes below
+    # shapes below (their CPU leg builds a 21-GB host copy of the lists: fine on the GPU box, not in a small container)
     "grouping-1B-pq16-nc993127-nsubc64-opq-pruning": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
-    # The 1B shapes of BASELINE.json configs[2] and [4] on ONE GPU (21 GB of lists; run with --no-cpu-baseline:
-    # the host copy of a 1B corpus is not built).  Parameters: examples/run_sift1b.sh:37-43 (the two paper
-    # points) and examples/run_deep1b_OPQ.sh.
+    # The 1B shapes of BASELINE.json configs[2] and [4] on ONE GPU (21 GB of lists; the CPU leg builds a host copy
+    # of them -- pass --no-cpu-baseline where 25 GB of host memory are not to spare).  Parameters:
+    # examples/run_sift1b.sh:37-43 (the two paper points) and examples/run_deep1b_OPQ.sh.
     "synthetic-1B-pq16-nc993127-nprobe32": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
     "synthetic-1B-pq16-nc993127-nprobe64": (1_000_000_000, 993127, 128, 16, 64, 30000, 100, 10000),
     "deep-1B-d96-opq-pq16-nc999973-nprobe128": (1_000_000_000, 999973, 96, 16, 128, 100000, 130, 10000),
