@@ -313,7 +313,7 @@ def main():
                                inter_centroid_dists=gt["inter_centroid_dists"])
             else:
                 ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h,
-                               ncodes_h, centroid_norms)
+                               ncodes_h, centroid_norms, opq_A=opq_A)
             ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
             log("[bench] host corpus for the CPU baseline: %.1fs" % (time.time() - t0))
             # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only spin
