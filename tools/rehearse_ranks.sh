@@ -1,0 +1,20 @@
+#!/bin/bash
+# N ranks of bench.py on ONE GPU over gloo against the single-rank run of the same scaled corpus: labels and
+# distance bits must agree.  usage: bash tools/rehearse_ranks.sh <N> [workload]
+set -e
+cd "$(dirname "$0")/.."
+N=${1:-4}; W=${2:-synthetic-100M-pq16-nc131072-nprobe32}
+mkdir -p gpurun_out
+python bench.py --gpus 1 --scale $N --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1 --workload $W --dump gpurun_out/reh_1.npz > gpurun_out/reh_1.log 2>&1
+echo "[rehearse] single rank done"
+IVFHNSW_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus $N --steps 3 --warmup 1 --workload $W --dump gpurun_out/reh_n.npz > gpurun_out/reh_n.log 2>&1
+echo "[rehearse] $N ranks done"
+python - <<'PY'
+import numpy as np
+a = np.load('gpurun_out/reh_1.npz'); b = np.load('gpurun_out/reh_n.npz')
+same_l = (a['labels'] == b['labels']).all(); same_d = (a['dist'].view('u4') == b['dist'].view('u4')).all()
+print("[rehearse] %d queries: labels equal %s, distance bits equal %s" % (len(a['labels']), same_l, same_d))
+raise SystemExit(0 if same_l and same_d else 1)
+PY
+rm -f gpurun_out/reh_1.npz gpurun_out/reh_n.npz
