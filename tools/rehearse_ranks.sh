@@ -1,6 +1,7 @@
 #!/bin/bash
 # N ranks of bench.py on ONE GPU over gloo against the single-rank run of the same scaled corpus: labels and
-# distance bits must agree.  usage: bash tools/rehearse_ranks.sh <N> [workload]
+# distance bits must agree (N <= 5: the box allows six processes on its GPU and the launcher counts).
+# usage: bash tools/rehearse_ranks.sh <N> [workload]
 set -e
 cd "$(dirname "$0")/.."
 N=${1:-4}; W=${2:-synthetic-100M-pq16-nc131072-nprobe32}
