@@ -598,8 +598,9 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     if (d % 16)
         return fail(IVFHNSW_ERR_INVALID, "d %zu: the reference distance ignores dims beyond a multiple of 16 "
                                          "(hnswalg.cpp:330); only multiples of 16 are supported here", d);
-    // link lists without repeated ids (every graph the reference builds): the walk may then enter a pass's
-    // survivors into the visited set late (kernels_hnsw.hip, filter_first)
+    // Link lists without repeated ids (every graph the reference builds) is what the walk's visited set assumes
+    // (kernels_hnsw.hip, VisFields).  A repeated id has no effect in the reference -- the second occurrence is
+    // skipped as visited (hnswalg.cpp:80-82) -- so lists that have them are uploaded without the repeats.
     bool unique = true;
     uint32_t tmp[256];
     for (size_t i = 0; i < n; i++) {
@@ -614,6 +615,29 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
             std::sort(tmp, tmp + c);
             unique = std::adjacent_find(tmp, tmp + c) == tmp + c;
         }
+    }
+    std::vector<uint8_t> counts_u;
+    std::vector<uint32_t> links_u;
+    if (!unique) {
+        counts_u.assign(link_counts, link_counts + n);
+        links_u.assign(links, links + n * maxM);
+        for (size_t i = 0; i < n; i++) {
+            uint32_t *row = links_u.data() + i * maxM;
+            size_t c = 0;
+            for (size_t j = 0; j < link_counts[i]; j++) {
+                bool seen = false;
+                for (size_t k2 = 0; k2 < c && !seen; k2++)
+                    seen = row[k2] == row[j];
+                if (!seen)
+                    row[c++] = row[j];
+            }
+            for (size_t j = c; j < link_counts[i]; j++)
+                row[j] = 0;
+            counts_u[i] = (uint8_t)c;
+        }
+        link_counts = counts_u.data();
+        links = links_u.data();
+        unique = true;
     }
     if ((rc = upload(h->q_counts, link_counts, n)))
         return rc;

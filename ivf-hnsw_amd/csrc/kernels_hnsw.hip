@@ -179,9 +179,9 @@ template <int NCH> struct RSet {
 // One wavefront (64-thread block) per resident slot; queries are taken from an atomic counter.
 // dynamic LDS: float query[d] | u64 tail[kTailCap]
 // Visited set (visited_list_pool.h:8-33 in the reference).  LDSVIS: an exact hash set in LDS -- kVisBuckets
-// buckets of four 16-bit tags (tag = id / kVisBuckets + 1, bucket = id % kVisBuckets), inserted with a 64-bit
-// compare-and-swap on the bucket; an id whose bucket is already full is recorded in the wave's global bitmap
-// instead (a few percent of the ids), and is looked up there from then on because a full bucket never empties.
+// 64-bit buckets of tags plus a claim count (VisFields below; tag = id / buckets + 1, bucket = id % buckets), an id
+// entered with one returning add and one or; an id whose bucket is already full is recorded in the wave's global
+// bitmap instead (a few percent of the ids), and is looked up there from then on because a full bucket never empties.
 // Why: one returning global atomicOr per neighbour on bitmaps that do not fit L2 was the walk's largest cost
 // (19.6 M scattered atomics per 10 k queries, ~1 ms; MI355X guide: scattered atomics run ~17x below the
 // coalesced rate).
@@ -195,11 +195,19 @@ constexpr int vis_buckets(int minw, int tagw = 8)
     return minw <= 4 ? (tagw == 10 ? 1040 : 896) : minw == 5 ? 768 : minw <= 7 ? 640 : 384;
 }
 
-// TAGW = bits per tag: 8 (8 tags per bucket, graphs up to 255 * 1024 nodes), 12 (5 per bucket, up to 4095 * 1024),
-// 16 (4 per bucket, up to 65535 * 1024); 0 = no LDS set, global bitmap only.  Fields are scanned SWAR-style:
-// haszero(v) = (v - ones) & ~v & highs flags the lowest zero field exactly (and is non-zero iff some field is zero).
+// TAGW = bits per tag; a 64-bit bucket holds `slots` tags and, in its top bits, the number of ids that claimed a
+// field:  8 -> 7 tags + 8-bit count (graphs up to 255 * buckets nodes), 10 -> 5 + 14, 12 -> 4 + 16, 16 -> 3 + 16;
+// 0 = no LDS set, global bitmap only.  Tags are scanned SWAR-style: haszero(v) = (v - ones) & ~v & highs is non-zero
+// iff some field of v is zero.
+// Insertion needs no compare-and-swap loop: an id not found in the bucket claims a field index with ONE returning
+// add on the count and ORs its tag into that (still zero) field -- two LDS instructions, no retry, where the CAS form
+// re-read the bucket whenever two lanes of a link list hashed to it.  This relies on the ids of one link list being
+// distinct (two equal ids in one instruction would both be entered and both reported new): the upload drops
+// repeated ids, which the reference skips as visited anyway (capi.cpp, upload_quantizer).
 template <int TAGW> struct VisFields {
-    static constexpr int slots = 64 / TAGW;
+    static constexpr int cntw = TAGW == 8 ? 8 : TAGW == 10 ? 14 : 16;
+    static constexpr int cshift = 64 - cntw;
+    static constexpr int slots = cshift / TAGW;
     static constexpr unsigned long long ones()
     {
         unsigned long long o = 0;
@@ -213,25 +221,26 @@ template <int TAGW, int NB>
 __device__ __forceinline__ bool visit_test_and_set(uint32_t id, unsigned long long *vt, uint32_t *bm, bool &used_bitmap)
 {
     if constexpr (TAGW != 0) {
-        constexpr unsigned long long kOnes = VisFields<TAGW>::ones();
+        using F = VisFields<TAGW>;
+        constexpr unsigned long long kOnes = F::ones();
         constexpr unsigned long long kHighs = kOnes << (TAGW - 1);
         const uint32_t b = id % (uint32_t)NB; // NB is a constant: multiply and shift
         const unsigned long long tag = (unsigned long long)((id / (uint32_t)NB) + 1);
-        for (;;) {
-            const unsigned long long old = vt[b];
-            const unsigned long long x = old ^ (tag * kOnes);
-            if ((x - kOnes) & ~x & kHighs)
-                return false; // some field equals the tag: seen before
-            const unsigned long long z = (old - kOnes) & ~old & kHighs; // lowest set bit = first empty field
-            if (!z)
-                break; // bucket full: this id lives in the bitmap
-            const int shift = (__ffsll((long long)z) - 1) - (TAGW - 1);
-            const unsigned long long want = old | (tag << shift);
-            if (atomicCAS(&vt[b], old, want) == old)
+        const unsigned long long old = vt[b];
+        const unsigned long long x = old ^ (tag * kOnes);
+        if ((x - kOnes) & ~x & kHighs)
+            return false; // some field equals the tag: seen before
+        // a full bucket never empties, and no lane adds to a count it has seen full: the count stays below
+        // slots + 64, far from wrapping
+        if ((uint32_t)(old >> F::cshift) < (uint32_t)F::slots) {
+            const unsigned long long got = atomicAdd(&vt[b], 1ull << F::cshift);
+            const uint32_t idx = (uint32_t)(got >> F::cshift);
+            if (idx < (uint32_t)F::slots) {
+                atomicOr(&vt[b], tag << (TAGW * idx));
                 return true;
-            // another lane changed the bucket in the meantime: look again
+            }
         }
-        used_bitmap = true;
+        used_bitmap = true; // bucket full: this id lives in the bitmap
     }
     const uint32_t bit = 1u << (id & 31);
     return !(atomicOr(&bm[id >> 5], bit) & bit);
@@ -252,8 +261,8 @@ __device__ __forceinline__ bool visit_lookup(uint32_t id, const unsigned long lo
     const unsigned long long x = old ^ (tag * kOnes);
     if ((x - kOnes) & ~x & kHighs)
         return true;
-    if ((old - kOnes) & ~old & kHighs)
-        return false; // a free field: everything that hashed here so far is in the bucket
+    if ((uint32_t)(old >> VisFields<TAGW>::cshift) < (uint32_t)VisFields<TAGW>::slots)
+        return false; // fields left: nothing that hashed here has gone to the bitmap
     return (atomicOr(&bm[id >> 5], 0u) >> (id & 31)) & 1u;
 }
 
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             // into the visited set: a row it rejects has dist >= bound > max(topResults), the maximum never grows
             // and the bound is a function of (row, query) alone, so the row is rejected again whenever it comes
             // back -- marking it visited (hnswalg.cpp:80-82) changes nothing.  The set then holds ~5 ids per
-            // expansion instead of ~27 (no bucket overflows, hardly any compare-and-swap retries), the membership
+            // expansion instead of ~27 (no bucket overflows), the membership
             // test is a plain LDS read, and the insertions of a pass's survivors wait until the NEXT expansion's
             // loads are in flight (just above the test, which must see them) -- off the dependent chain.  Needs
             // link lists without repeated ids (checked at upload): a repeated survivor would be entered twice.
