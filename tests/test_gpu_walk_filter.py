@@ -99,8 +99,8 @@ def test_degree_beyond_one_row_batch(gpu):
 
 def test_link_lists_with_repeated_ids(gpu):
     """The same neighbour twice in a link list (never in a graph the reference built, but an uploaded one may): the
-    second occurrence counts as visited (hnswalg.cpp:80-82), also where the walk enters the pass's survivors into
-    the visited set only after their rows were requested."""
+    second occurrence counts as visited (hnswalg.cpp:80-82) -- the device's visited set assumes distinct ids per
+    list, so the upload drops the repeats; results must be those of the oracle walking the lists as given."""
     rng = np.random.default_rng(115)
     cents = synth.sift_like(rng, 4096, 128)
     built = orc.Hnsw.build(cents, M=16, efConstruction=60)
@@ -160,7 +160,7 @@ print("LATE OK", len(made))
 def test_late_visit_form_in_a_child_process():
     """The form the walk takes on graphs beyond 228 k nodes (survivors of the filter entered into the visited set at
     the next expansion; IVFHNSW_WALK_LATE_VISIT=1 forces it, read once per process): the cases above again.  Link
-    lists with repeated ids must fall back to the early test by themselves."""
+    lists with repeated ids are uploaded without the repeats (the reference skips them as visited)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ, IVFHNSW_WALK_LATE_VISIT="1")
     r = subprocess.run([sys.executable, "-c", LATE_CHILD % dict(root=root)], capture_output=True, text=True, env=e,
