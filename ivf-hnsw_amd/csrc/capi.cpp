@@ -661,14 +661,14 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     }
     {
         // IVFHNSW_WALK_LATE_VISIT: 1 always, 0 never, unset = where it pays -- graphs whose ids need more than 8 tag
-        // bits (beyond 255 * 896 nodes), where the visited set of a query would otherwise run 40 % full and
+        // bits (beyond 255 * 1008 nodes), where the visited set of a query would otherwise run 40 % full and
         // overflow into global atomics (1.60 -> 1.50 ms per 10 k queries at 993 127 nodes; at 2^17 nodes the extra
         // LDS pass costs 1 %: 1.19 -> 1.205 ms)
         static const int late_knob = [] {
             const char *e = getenv("IVFHNSW_WALK_LATE_VISIT");
             return e ? (atoi(e) != 0 ? 1 : 0) : -1;
         }();
-        const bool late = late_knob < 0 ? n > 255u * 896u : late_knob == 1;
+        const bool late = late_knob < 0 ? n > 255u * 1008u : late_knob == 1;
         h->gr.links_unique = (unique && late) ? 1 : 0;
     }
     h->gr.qrows = nullptr;

@@ -186,13 +186,14 @@ template <int NCH> struct RSet {
 // (19.6 M scattered atomics per 10 k queries, ~1 ms; MI355X guide: scattered atomics run ~17x below the
 // coalesced rate).
 // The bucket count follows the occupancy the kernel is built for (MINW waves per SIMD, 4 * MINW per CU sharing
-// 160 KB of LDS): 7 KB of buckets at 4 (with the merge buffer below that is 10 KB per wave), 6 KB at 5, 5 KB at 6.
+// 160 KB of LDS): 1008 buckets = 7.9 KB at 4 (with query, planes, tail and merge buffer 9.8 KB per wave at efSearch 80:
+// sixteen waves fill 157 of a CU's 160 KB), 6 KB at 5, 5 KB at 6.
 constexpr int vis_buckets(int minw, int tagw = 8)
 {
     // 10-bit tags (six per bucket) exist for graphs of about a million nodes -- the reference's 993 127 centroids,
     // the 2^20 of the 8-GPU bench: with 12-bit tags (five per bucket) 896 buckets ran 56 % full and every
     // expansion paid a global atomic for an overflowing neighbour.  1040 buckets x 6 = 6240 slots, 8320 bytes.
-    return minw <= 4 ? (tagw == 10 ? 1040 : 896) : minw == 5 ? 768 : minw <= 7 ? 640 : 384;
+    return minw <= 4 ? (tagw == 10 ? 1040 : 1008) : minw == 5 ? 768 : minw <= 7 ? 640 : 384;
 }
 
 // TAGW = bits per tag; a 64-bit bucket holds `slots` tags and, in its top bits, the number of ids that claimed a
