@@ -59,7 +59,7 @@ def test_every_knob_setting_reproduces_the_default_path():
                 {"IVFHNSW_WALK_VIS": "bitmap"},      # global visited bitmaps
                 {"IVFHNSW_WALK_OCC": "5"}, {"IVFHNSW_WALK_OCC": "6"},
                 {"IVFHNSW_WALK_TAGW": "10"}, {"IVFHNSW_WALK_TAGW": "12"}, {"IVFHNSW_WALK_TAGW": "16"},  # visited-set tag widths
-                # survivors of the filter entered into the visited set late (default only beyond 228 k nodes)
+                # survivors of the filter entered into the visited set late (default only beyond 257 k nodes)
                 {"IVFHNSW_WALK_LATE_VISIT": "1"}, {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "10"},
                 {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "16"}, {"IVFHNSW_WALK_LATE_VISIT": "0"},
                 {"IVFHNSW_SCAN_SHORT": "0"},         # Grouping plans through the position form of the scan

@@ -158,7 +158,7 @@ print("LATE OK", len(made))
 
 
 def test_late_visit_form_in_a_child_process():
-    """The form the walk takes on graphs beyond 228 k nodes (survivors of the filter entered into the visited set at
+    """The form the walk takes on graphs beyond 257 k nodes (survivors of the filter entered into the visited set at
     the next expansion; IVFHNSW_WALK_LATE_VISIT=1 forces it, read once per process): the cases above again.  Link
     lists with repeated ids are uploaded without the repeats (the reference skips them as visited)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
