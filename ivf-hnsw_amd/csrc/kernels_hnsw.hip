@@ -247,11 +247,34 @@ __device__ __forceinline__ bool visit_test_and_set(uint32_t id, unsigned long lo
     return !(atomicOr(&bm[id >> 5], bit) & bit);
 }
 
+// Insertion of an id the caller KNOWS to be absent (visit_lookup said so and nothing was entered since): no read,
+// just the claim and the or.  `bucket_full` is what that lookup saw: a full bucket is not added to any more, which
+// keeps every count below slots + 64 (one instruction's worth of lanes), far from wrapping.
+template <int TAGW, int NB>
+__device__ __forceinline__ void visit_insert_absent(uint32_t id, bool bucket_full, unsigned long long *vt, uint32_t *bm,
+                                                    bool &used_bitmap)
+{
+    static_assert(TAGW != 0, "LDS set only");
+    using F = VisFields<TAGW>;
+    if (!bucket_full) {
+        const uint32_t b = id % (uint32_t)NB;
+        const unsigned long long tag = (unsigned long long)((id / (uint32_t)NB) + 1);
+        const unsigned long long got = atomicAdd(&vt[b], 1ull << F::cshift);
+        const uint32_t idx = (uint32_t)(got >> F::cshift);
+        if (idx < (uint32_t)F::slots) {
+            atomicOr(&vt[b], tag << (TAGW * idx));
+            return;
+        }
+    }
+    used_bitmap = true;
+    atomicOr(&bm[id >> 5], 1u << (id & 31));
+}
+
 // Read-only membership test of the LDS set (TAGW != 0).  An id whose bucket is full may live in the wave's bitmap:
 // read through a returning atomic, which sees the atomicOr of earlier insertions (a plain load could hit a stale
 // L1 line).
 template <int TAGW, int NB>
-__device__ __forceinline__ bool visit_lookup(uint32_t id, const unsigned long long *vt, uint32_t *bm)
+__device__ __forceinline__ bool visit_lookup(uint32_t id, const unsigned long long *vt, uint32_t *bm, bool &bucket_full)
 {
     static_assert(TAGW != 0, "LDS set only");
     constexpr unsigned long long kOnes = VisFields<TAGW>::ones();
@@ -260,9 +283,11 @@ __device__ __forceinline__ bool visit_lookup(uint32_t id, const unsigned long lo
     const unsigned long long tag = (unsigned long long)((id / (uint32_t)NB) + 1);
     const unsigned long long old = vt[b];
     const unsigned long long x = old ^ (tag * kOnes);
+    bucket_full = false;
     if ((x - kOnes) & ~x & kHighs)
         return true;
-    if ((uint32_t)(old >> VisFields<TAGW>::cshift) < (uint32_t)VisFields<TAGW>::slots)
+    bucket_full = (uint32_t)(old >> VisFields<TAGW>::cshift) >= (uint32_t)VisFields<TAGW>::slots;
+    if (!bucket_full)
         return false; // fields left: nothing that hashed here has gone to the bitmap
     return (atomicOr(&bm[id >> 5], 0u) >> (id & 31)) & 1u;
 }
@@ -494,7 +519,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         }
         bool used_bitmap = false;
         // survivors of the last pass, entered into the visited set at the top of the next expansion
-        bool pend = false, pend_any = false;
+        bool pend = false, pend_any = false, pend_full = false;
         uint32_t pend_id = 0;
         if (STAMPS) {
             const unsigned long long t = walk_stamp();
@@ -582,16 +607,16 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             // link lists without repeated ids (checked at upload): a repeated survivor would be entered twice.
             constexpr bool LATE = FMODE == 3 && LDSVIS; // the launcher picks it only for GraphTables::links_unique
             const bool filter_first = LATE && filter_now;
-            bool fresh = false, seen = false;
+            bool fresh = false, seen = false, full_now = false;
             if constexpr (LATE) {
                 if (pend_any) {
                     if (pend)
-                        (void)visit_test_and_set<TAGW, NB>(pend_id, vt, bm, used_bitmap);
+                        visit_insert_absent<TAGW, NB>(pend_id, pend_full, vt, bm, used_bitmap);
                     pend_any = false;
                 }
                 if (lane < cnt) {
                     if (filter_first)
-                        seen = visit_lookup<TAGW, NB>(nb, vt, bm);
+                        seen = visit_lookup<TAGW, NB>(nb, vt, bm, full_now);
                     else
                         fresh = visit_test_and_set<TAGW, NB>(nb, vt, bm, used_bitmap);
                 }
@@ -675,6 +700,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 nfresh = __popcll(mask);
                 if (filter_first) {
                     pend = fresh;
+                    pend_full = full_now;
                     pend_id = nb;
                     pend_any = nfresh > 0;
                 }
