@@ -60,13 +60,18 @@ __device__ __forceinline__ int take8_set_bits(unsigned long long &m, int lane)
     // only lanes without a row ever see)
     uint32_t lo = 0, hi = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 4; j++) {
         const uint32_t p = (uint32_t)__builtin_ctzll(m | (1ull << 63));
-        if (j < 4)
-            lo |= p << (8 * j);
-        else
-            hi |= p << (8 * (j - 4));
+        lo |= p << (8 * j);
         m &= ~(1ull << p);
+    }
+    if (m) { // wave-uniform: a pass usually has fewer than five rows
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t p = (uint32_t)__builtin_ctzll(m | (1ull << 63));
+            hi |= p << (8 * j);
+            m &= ~(1ull << p);
+        }
     }
     const uint32_t w = (lane & 32) ? hi : lo;
     return (int)((w >> (8 * ((lane >> 3) & 3))) & 0xffu);
@@ -102,6 +107,27 @@ __device__ __forceinline__ int oct_sum4(const int (&S)[4], int lane)
     int c = k + __builtin_amdgcn_update_dpp(0, h, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
     c += __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, true);        // quad_perm [2,3,0,1]: same value index there
     return c;
+}
+
+// oct_sum4 of two value sets at once, step by step in turn: each DPP add of one chain fills the wait states the
+// other chain's DPP operand needs (the compiler pads a lone chain with s_nop).
+__device__ __forceinline__ void oct_sum4x2(const int (&S)[4], const int (&X)[4], int lane, int &s_out, int &x_out)
+{
+    const bool b2 = (lane & 4) != 0, b0 = (lane & 1) != 0;
+    const int sk0 = b2 ? S[2] : S[0], sk1 = b2 ? S[3] : S[1], sh0 = b2 ? S[0] : S[2], sh1 = b2 ? S[1] : S[3];
+    const int xk0 = b2 ? X[2] : X[0], xk1 = b2 ? X[3] : X[1], xh0 = b2 ? X[0] : X[2], xh1 = b2 ? X[1] : X[3];
+    const int sa0 = sk0 + __builtin_amdgcn_update_dpp(0, sh0, 0x141, 0xf, 0xf, true);
+    const int xa0 = xk0 + __builtin_amdgcn_update_dpp(0, xh0, 0x141, 0xf, 0xf, true);
+    const int sa1 = sk1 + __builtin_amdgcn_update_dpp(0, sh1, 0x141, 0xf, 0xf, true);
+    const int xa1 = xk1 + __builtin_amdgcn_update_dpp(0, xh1, 0x141, 0xf, 0xf, true);
+    const int sk = b0 ? sa1 : sa0, sh = b0 ? sa0 : sa1;
+    const int xk = b0 ? xa1 : xa0, xh = b0 ? xa0 : xa1;
+    int sc = sk + __builtin_amdgcn_update_dpp(0, sh, 0xB1, 0xf, 0xf, true);
+    int xc = xk + __builtin_amdgcn_update_dpp(0, xh, 0xB1, 0xf, 0xf, true);
+    sc += __builtin_amdgcn_update_dpp(0, sc, 0x4E, 0xf, 0xf, true);
+    xc += __builtin_amdgcn_update_dpp(0, xc, 0x4E, 0xf, 0xf, true);
+    s_out = sc;
+    x_out = xc;
 }
 
 // Exact reference distance (hnswalg.cpp:326-357) of one row evaluated by a QUAD of lanes: lane t of the quad

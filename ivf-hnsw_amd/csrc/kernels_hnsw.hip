@@ -646,14 +646,17 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     for (int i = 0; i < 4; i++) {
                         // 128 * (row.row - 2 (Q/256).row), exact in integers; 128 * Q.Q / 65536 joins below
                         const uint32_t ws[4] = {nw[i].x, nw[i].y, nw[i].z, nw[i].w};
-                        uint32_t hr = 0, lr = 0, rr = 0;
+                        uint32_t hr = 0, rr = 0;
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             hr = __builtin_amdgcn_udot4(qh[c], ws[c], hr, false);
-                            lr = __builtin_amdgcn_udot4(ql[c], ws[c], lr, false);
                             rr = __builtin_amdgcn_udot4(ws[c], ws[c], rr, false);
                         }
-                        S[i] = (int)(128u * rr - 256u * hr - lr); // this lane's 16 bytes of row rb + 8i + (lane >> 3)
+                        uint32_t lr = hr << 8; // the lo plane's sum accumulates on top of 256 * hr
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+                            lr = __builtin_amdgcn_udot4(ql[c], ws[c], lr, false);
+                        S[i] = (int)(128u * rr - lr); // this lane's 16 bytes of row rb + 8i + (lane >> 3)
                         X[i] = 0;
                         if (x_any) { // wave-uniform (scalar): SIFT-like queries only ever leave the range downwards
                             uint32_t xlr = 0, xhr = 0;
@@ -674,8 +677,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     // instead of 12 for four full group sums); that lane evaluates the bound, one ballot collects
                     // the verdicts of the lanes with bit1(ii) = 0, and link lane L (row L - rb = 8i + G) reads bit
                     // 8G + 4 (i >> 1) + (i & 1) of it -- no cross-lane traffic through the LDS crossbar.
-                    const int mine = oct_sum4(S, lane);
-                    const int minex = x_any ? oct_sum4(X, lane) : 0;
+                    int mine, minex = 0;
+                    if (x_any)
+                        oct_sum4x2(S, X, lane, mine, minex);
+                    else
+                        mine = oct_sum4(S, lane);
                     // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: the factors 1 - 2^-10 cover it
                     const float m1 = fmaxf(
                         0.f, __builtin_amdgcn_sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
