@@ -797,9 +797,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     int cand_below = 0, set_below = 0;
                     for (unsigned long long cm = cand; cm; cm &= cm - 1) {
                         const int b = __ffsll((long long)cm) - 1;
-                        const unsigned long long Kj =
-                            mk_key(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b)),
-                                   (uint32_t)__builtin_amdgcn_readlane((int)nbq, b));
+                        const unsigned long long Kj = readlane_u64(Kc, b); // lane b's key, built once per lane above
                         int below = 0;
 #pragma unroll
                         for (int cc = 0; cc < NCH; cc++) {
