@@ -626,11 +626,14 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
             unsigned long long mask = __ballot(fresh);
             int nfresh = __popcll(mask);
+            // the set's last entry: read once per expansion, for the filter and for the first pass below (the set
+            // does not change in between)
+            const unsigned long long last_now = R.get(n - 1);
             if (filter_now && inline_rows) {
                 if (filter_first)
                     fresh = lane < cnt && !seen;
                 // (see the gather form below for the bound)  Link lane L is row L of the node's block.
-                const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                const float worst = __uint_as_float(key_dist_bits(last_now));
                 // hi / lo / XL planes: this lane's 16 bytes of each live in registers for the whole query (qp_*, set
                 // where the planes are built); XH, rarely non-zero, is read when needed
                 const uint32_t qh[4] = {qp_h.x, qp_h.y, qp_h.z, qp_h.w}, ql[4] = {qp_l.x, qp_l.y, qp_l.z, qp_l.w};
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 // shrunk by 2^-10 twice, which covers every rounding on either side (d <= 2048: the float sums
                 // are within (d+2) * 2^-24 of the real ones).  Rejected rows stay marked visited, as in the
                 // reference; everything else takes the float path below unchanged.
-                const float worst = __uint_as_float(key_dist_bits(R.get(n - 1)));
+                const float worst = __uint_as_float(key_dist_bits(last_now));
                 const int myrow = __popcll(mask & ((1ull << lane) - 1ull)); // row index of this link lane
                 for (int base = 0; base < nfresh; base += 32) {
                     const int r = base + (lane >> 1);
@@ -770,7 +773,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 // Rows that cannot be admitted are dropped wave-wide before the sequential part: once the
                 // set is full its maximum only decreases, so a row failing 'top > dist' (hnswalg.cpp:93)
                 // against the current maximum fails against every later one too.
-                unsigned long long topk = R.get(n - 1); // the set's last entry, carried through the loop
+                unsigned long long topk = base == 0 ? last_now : R.get(n - 1); // the set's last entry, carried through the loop
                 const float top0 = __uint_as_float(key_dist_bits(topk));
                 // (first lane of each row's group, rows that exist: constant and scalar masks instead of per-lane tests)
                 unsigned long long cand = (n < ef ? ~0ull : __ballot(top0 > dq)) & 0x0101010101010101ull &
