@@ -86,7 +86,7 @@ struct ivfhnsw_gpu {
     DevBuf g_alpha, g_nn, g_sizes, g_inter;
     GroupTables g{};
     bool has_group = false;
-    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows;
+    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms;
     GraphTables gr{};
     bool has_graph = false;
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
@@ -335,7 +335,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
@@ -577,9 +577,12 @@ static int build_neighbour_rows(ivfhnsw_gpu *h)
     int rc = h->q_nbrows.ensure(bytes);
     if (rc)
         return rc;
-    HIP_TRY(launch_build_nbrows(h->stream, h->gr, h->q_nbrows.as<uint8_t>(), nb_rows));
+    if ((rc = h->q_nbnorms.ensure((size_t)h->gr.n * nb_rows * sizeof(uint32_t))))
+        return rc;
+    HIP_TRY(launch_build_nbrows(h->stream, h->gr, h->q_nbrows.as<uint8_t>(), h->q_nbnorms.as<uint32_t>(), nb_rows));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->gr.nbrows = h->q_nbrows.as<uint8_t>();
+    h->gr.nbnorms = h->q_nbnorms.as<uint32_t>();
     h->gr.nb_rows = nb_rows;
     return IVFHNSW_OK;
 }
@@ -673,6 +676,7 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     }
     h->gr.qrows = nullptr;
     h->gr.nbrows = nullptr;
+    h->gr.nbnorms = nullptr;
     h->gr.nb_rows = 0;
     h->gr.q_lo = 0.f;
     h->gr.q_step = 1.f;
@@ -1299,7 +1303,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

@@ -70,6 +70,7 @@ struct GraphTables {
     // neighbours, [n][nb_rows][128] with nb_rows = maxM rounded up to 32, zero padded.  One contiguous
     // nb_rows*128-byte read per expansion, issued together with the link list.  NULL = gather from qrows.
     const uint8_t *nbrows;
+    const uint32_t *nbnorms; // [n][nb_rows] sum of bytes^2 of every neighbour row (the filter's ||c||^2 term)
     int nb_rows;
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
     int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
@@ -139,7 +140,7 @@ hipError_t launch_group_alpha(hipStream_t s, const unsigned long long *offsets, 
 hipError_t launch_group_rows(hipStream_t s, const unsigned long long *offsets, const uint32_t *sub, uint32_t *rows,
                              size_t ngroups, int nsubc);
 // nbrows[i][j] = qrows[links[i][j]] for j < counts[i], zero otherwise (GraphTables::nbrows)
-hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows);
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows);
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
 hipError_t launch_fill_lists(hipStream_t s, const IvfTables &t, uint8_t *codes, uint8_t *norm_codes, uint32_t *ids,

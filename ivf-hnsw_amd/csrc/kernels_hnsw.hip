@@ -366,9 +366,16 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     constexpr bool LDSVIS = TAGW != 0;
 
     const int lane = threadIdx.x;
+    // the row of a 32-row batch whose bound this lane evaluates in the filter (oct_sum4's layout)
+    const int judged_row = 8 * (((lane >> 2) & 1) * 2 + (lane & 1)) + (lane >> 3);
     const bool merge_on = g.merge_admissions != 0;
     constexpr bool prefilter = FMODE != 0;
     constexpr bool inline_rows = FMODE >= 2;
+    // The rows' squared norms from a table built at upload (one more dword load per expansion) instead of sixteen
+    // v_dot4 of each row with itself: measured on one box, 1.438 -> 1.384 ms per 10 k queries at 993 127 nodes, but
+    // 1.085 -> 1.103 ms at 2^17 nodes, where the load's wait costs more than the instructions -- so it goes with
+    // the form large graphs take.
+    constexpr bool ROWNORMS = FMODE == 3;
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
     bool bitmap_dirty = true; // the bitmap must be wiped before its first use and after any query that used it
 
@@ -591,11 +598,14 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             // chunk lane & 7 -- four 1 KiB wave reads, in flight together with the link list
             const bool filter_now = prefilter && n == ef;
             uint4 nw[4] = {};
+            uint32_t row_rr = 0; // sum of bytes^2 of the row this lane will judge (row 8 * (2 bit2 + bit0) + group)
             if (filter_now && inline_rows) {
                 const uint4 *nbr = reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + lane;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     nw[i] = nbr[i * 64];
+                if constexpr (ROWNORMS)
+                    row_rr = g.nbnorms[(size_t)node * g.nb_rows + judged_row];
             }
             // With the neighbour-row filter on (and the LDS set), only the rows the filter lets through are ENTERED
             // into the visited set: a row it rejects has dist >= bound > max(topResults), the maximum never grows
@@ -653,13 +663,16 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             hr = __builtin_amdgcn_udot4(qh[c], ws[c], hr, false);
-                            rr = __builtin_amdgcn_udot4(ws[c], ws[c], rr, false);
+                            if constexpr (!ROWNORMS)
+                                rr = __builtin_amdgcn_udot4(ws[c], ws[c], rr, false);
                         }
                         uint32_t lr = hr << 8; // the lo plane's sum accumulates on top of 256 * hr
 #pragma unroll
                         for (int c = 0; c < 4; c++)
                             lr = __builtin_amdgcn_udot4(ql[c], ws[c], lr, false);
-                        S[i] = (int)(128u * rr - lr); // this lane's 16 bytes of row rb + 8i + (lane >> 3)
+                        // this lane's 16 bytes of row rb + 8i + (lane >> 3); with ROWNORMS 128 * row.row
+                        // (GraphTables::nbnorms, computed at upload) joins after the group sum instead
+                        S[i] = (int)(128u * rr - lr);
                         X[i] = 0;
                         if (x_any) { // wave-uniform (scalar): SIFT-like queries only ever leave the range downwards
                             uint32_t xlr = 0, xhr = 0;
@@ -686,6 +699,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     else
                         mine = oct_sum4(S, lane);
                     // v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence: the factors 1 - 2^-10 cover it
+                    mine += (int)(128u * row_rr);
                     const float m1 = fmaxf(
                         0.f, __builtin_amdgcn_sqrtf((float)(mine + q16_w) * 0.0078125f) * 0.9990234375f - pf_slack_q);
                     const float m2 = fmaf(m1, m1, fmaf((float)(minex + x_const), 0.9990234375f, pf_bonus));
@@ -704,6 +718,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         nw[i] = nbr[i * 64];
+                    if constexpr (ROWNORMS)
+                        row_rr = g.nbnorms[(size_t)node * g.nb_rows + rb + judged_row];
                 }
                 mask = __ballot(fresh);
                 nfresh = __popcll(mask);
@@ -903,7 +919,10 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 }
 
 // one 64-thread block per (node, 8 rows): lane -> row (lane >> 3), 16-byte chunk (lane & 7)
-__global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t *__restrict__ nbrows, int nb_rows)
+// ... and the rows' squared norms (sum of bytes^2, u32 [n][nb_rows]): the walk's filter needs them per row, and a
+// dword load per row is cheaper there than sixteen v_dot4 of the row with itself
+__global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t *__restrict__ nbrows,
+                                                          uint32_t *__restrict__ nbnorms, int nb_rows)
 {
     const size_t node = blockIdx.x;
     const int cnt = g.counts[node];
@@ -914,14 +933,22 @@ __global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t
         if (r < cnt && c < cpr)
             v = reinterpret_cast<const uint4 *>(g.qrows + (size_t)g.links[node * g.maxM + r] * g.d)[c];
         reinterpret_cast<uint4 *>(nbrows + (node * nb_rows + r) * 128)[c] = v;
+        uint32_t rr = 0;
+        rr = __builtin_amdgcn_udot4(v.x, v.x, rr, false);
+        rr = __builtin_amdgcn_udot4(v.y, v.y, rr, false);
+        rr = __builtin_amdgcn_udot4(v.z, v.z, rr, false);
+        rr = __builtin_amdgcn_udot4(v.w, v.w, rr, false);
+        rr = (uint32_t)oct_sum((int)rr);
+        if (c == 0)
+            nbnorms[node * nb_rows + r] = rr;
     }
 }
 
-hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, int nb_rows)
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows)
 {
     if (!g.qrows || g.d > 128 || (g.d & 15) || nb_rows < g.maxM || (nb_rows & 31))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(build_nbrows_kernel, dim3(g.n), dim3(64), 0, s, g, nbrows, nb_rows);
+    hipLaunchKernelGGL(build_nbrows_kernel, dim3(g.n), dim3(64), 0, s, g, nbrows, nbnorms, nb_rows);
     return hipGetLastError();
 }
 
