@@ -63,7 +63,7 @@ def main():
     t = (time.perf_counter() - t0) / 5
     st = {a: round(b[0] / 5, 3) for a, b in g.stage_ms().items()}
     print("world %d: one rank's compute per step %.3f ms -> %.2f M queries/s aggregate if collectives were free "
-          "(N=1 measures 1.64 ms for 10 k); stages %s; codes scored here per step %d"
+          "(N=1 measures 1.53 ms for 10 k); stages %s; codes scored here per step %d"
           % (W, t * 1e3, nq / t / 1e6, st, g.last_scan_counts()[0]), flush=True)
 
 
