@@ -61,9 +61,12 @@ int ivfhnsw_gpu_sync(ivfhnsw_gpu *h);
  * list c occupies [offsets[c], offsets[c+1]) of ids / norm_codes and code_size times that of codes,
  * in list order (the scan order decides ties, IndexIVF_HNSW.cpp:285).
  *
- * Sharding: with shard_world > 1 the arrays ids/codes/norm_codes hold only the lists
- * with c % shard_world == shard_rank, concatenated in increasing c; offsets is always the global
- * table, so every shard derives the same scan plan. */
+ * Sharding: with shard_world > 1 the arrays ids/codes/norm_codes hold only the lists this
+ * shard owns, concatenated in increasing c; offsets is always the global table, so every shard derives
+ * the same scan plan.  List c is owned by rank list_owner[c]; with list_owner == NULL by rank
+ * c % shard_world.  The owner table lets the caller keep the lists a query probes together on few ranks
+ * (a balanced spatial partition of the centroids), so that a query's table is built and staged on those
+ * ranks only. */
 typedef struct ivfhnsw_ivf_desc {
     size_t d;                    /* IndexIVF_HNSW.h:50 */
     size_t nc;                   /* :51 */
@@ -77,6 +80,7 @@ typedef struct ivfhnsw_ivf_desc {
     const float *norm_table;     /* norm_pq->centroids, [256] (:57) */
     const float *opq_A;          /* opq_matrix->A, [d][d] row major, or NULL when !do_opq (:58-59) */
     uint32_t shard_rank, shard_world; /* 0, 1 for a single GPU */
+    const uint32_t *list_owner;  /* [nc] owning rank of every list (< shard_world), or NULL = c % shard_world */
 } ivfhnsw_ivf_desc;
 int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *desc);
 

@@ -34,7 +34,7 @@ class IvfDesc(C.Structure):
                 ("offsets", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p),
                 ("norm_codes", C.c_void_p), ("centroid_norms", C.c_void_p), ("pq_centroids", C.c_void_p),
                 ("norm_table", C.c_void_p), ("opq_A", C.c_void_p),
-                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
+                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("list_owner", C.c_void_p)]
 
 
 class SearchParams(C.Structure):
@@ -156,7 +156,7 @@ class GpuIndex:
 
     # ---- uploads -------------------------------------------------------------------------------
     def _desc(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, ids, codes, norm_codes,
-              shard_rank, shard_world):
+              shard_rank, shard_world, list_owner=None):
         keep = {}
         keep["offsets"] = _np(offsets, np.uint64)
         nc = len(keep["offsets"]) - 1
@@ -170,22 +170,25 @@ class GpuIndex:
         keep["ids"] = None if ids is None else _np(ids, np.uint32)
         keep["codes"] = None if codes is None else _np(codes, np.uint8)
         keep["norm_codes"] = None if norm_codes is None else _np(norm_codes, np.uint8)
+        keep["list_owner"] = None if list_owner is None else _np(list_owner, np.uint32)
+        assert keep["list_owner"] is None or keep["list_owner"].size == nc
         desc = IvfDesc(d, nc, code_size, _ptr(keep["offsets"]), _ptr(keep["ids"]), _ptr(keep["codes"]),
                        _ptr(keep["norm_codes"]), _ptr(keep["centroid_norms"]), _ptr(keep["pq_centroids"]),
-                       _ptr(keep["norm_table"]), _ptr(keep["opq_A"]), shard_rank, shard_world)
+                       _ptr(keep["norm_table"]), _ptr(keep["opq_A"]), shard_rank, shard_world,
+                       _ptr(keep["list_owner"]))
         self.d, self.nc, self.code_size = d, nc, code_size
         return desc, keep
 
     def upload_ivf(self, d, code_size, offsets, ids, codes, norm_codes, centroid_norms, pq_centroids, norm_table,
-                   opq_A=None, shard_rank=0, shard_world=1):
+                   opq_A=None, shard_rank=0, shard_world=1, list_owner=None):
         desc, keep = self._desc(d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, ids, codes,
-                                norm_codes, shard_rank, shard_world)
+                                norm_codes, shard_rank, shard_world, list_owner)
         _check(lib().ivfhnsw_gpu_upload_ivf(self._h, C.byref(desc)))
 
     def upload_ivf_synthetic(self, d, code_size, offsets, centroid_norms, pq_centroids, norm_table, seed, opq_A=None,
-                             shard_rank=0, shard_world=1):
+                             shard_rank=0, shard_world=1, list_owner=None):
         desc, keep = self._desc(d, code_size, offsets, centroid_norms, pq_centroids, norm_table, opq_A, None, None,
-                                None, shard_rank, shard_world)
+                                None, shard_rank, shard_world, list_owner)
         _check(lib().ivfhnsw_gpu_upload_ivf_synthetic(self._h, C.byref(desc), seed))
 
     def upload_grouping(self, nsubc, alphas, nn_centroid_idxs, subgroup_sizes, inter_centroid_dists):

@@ -207,8 +207,9 @@ int check_desc(const ivfhnsw_ivf_desc *d, bool need_lists)
         return fail(IVFHNSW_ERR_INVALID, "d, nc and code_size must be positive");
     if (d->code_size % 4)
         return fail(IVFHNSW_ERR_INVALID, "code_size %zu is not a multiple of 4 (IndexIVF_HNSW.cpp:805)", d->code_size);
-    if (d->code_size != 4 && d->code_size != 8 && d->code_size != 16 && d->code_size != 32)
-        return fail(IVFHNSW_ERR_INVALID, "code_size %zu unsupported (4, 8, 16, 32)", d->code_size);
+    if (d->code_size * 1024 > kScanDynLdsMax)
+        return fail(IVFHNSW_ERR_INVALID, "code_size %zu: the query's table (1 KB per code byte) must fit %zu KB of LDS",
+                    d->code_size, kScanDynLdsMax / 1024);
     if (d->d % d->code_size)
         return fail(IVFHNSW_ERR_INVALID, "d %zu is not a multiple of code_size %zu", d->d, d->code_size);
     if (d->d / d->code_size > 64)
@@ -232,18 +233,21 @@ int check_desc(const ivfhnsw_ivf_desc *d, bool need_lists)
 // Tables shared by upload_ivf and upload_ivf_synthetic; fills h->t except codes/norm_codes/ids.
 int upload_tables(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, std::vector<uint32_t> &loff, uint64_t &n_local)
 {
-    loff.assign(d->nc, 0);
+    loff.assign(d->nc, kNotOwned);
     n_local = 0;
     for (size_t c = 0; c < d->nc; c++) {
-        if (c % d->shard_world != d->shard_rank)
+        const uint32_t owner = d->list_owner ? d->list_owner[c] : (uint32_t)(c % d->shard_world);
+        if (owner >= d->shard_world)
+            return fail(IVFHNSW_ERR_INVALID, "list_owner[%zu] = %u is not a rank of %u", c, owner, d->shard_world);
+        if (owner != d->shard_rank)
             continue;
-        if (n_local > 0xffffffffull)
-            return fail(IVFHNSW_ERR_INVALID, "more than 2^32 codes on one shard");
+        if (n_local >= 0xffffffffull)
+            return fail(IVFHNSW_ERR_INVALID, "2^32 - 1 or more codes on one shard");
         loff[c] = (uint32_t)n_local;
         n_local += d->offsets[c + 1] - d->offsets[c];
     }
-    if (n_local > 0xffffffffull)
-        return fail(IVFHNSW_ERR_INVALID, "more than 2^32 codes on one shard");
+    if (n_local >= 0xffffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "2^32 - 1 or more codes on one shard");
     int rc;
     if ((rc = upload(h->goff, d->offsets, (d->nc + 1) * sizeof(uint64_t))))
         return rc;
@@ -287,7 +291,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 6; }
+int ivfhnsw_gpu_abi_version(void) { return 7; }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {

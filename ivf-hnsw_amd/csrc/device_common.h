@@ -365,4 +365,44 @@ __device__ __forceinline__ float adc_sum(const float *s_lut, const uint32_t (&w)
     return sum;
 }
 
+// One code's bytes between its load and its use.  CS > 0: the code words stay in registers (all loads of an unrolled
+// step are issued before the first table lookup).  CS == 0 is the run-time form for code sizes without an
+// instantiation of their own (any multiple of 4, IndexIVF_HNSW.cpp:805): the sum is taken word by word as the code
+// is read, in the same m order.
+template <int CS> struct CodeRegs {
+    uint32_t w[CS / 4];
+};
+template <> struct CodeRegs<0> {
+    float sum;
+};
+
+template <int CS>
+__device__ __forceinline__ void code_fetch(const uint8_t *__restrict__ codes, uint32_t gi, int cs_rt, const float *s_lut,
+                                           CodeRegs<CS> &r)
+{
+    if constexpr (CS > 0) {
+        load_code_words<CS>(codes, gi, r.w);
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(codes + (size_t)gi * cs_rt);
+        float sum = 0.0f;
+        for (int j = 0; j < cs_rt / 4; j++) {
+            const uint32_t w = p[j];
+            const float *t = s_lut + j * 1024;
+            sum = __fadd_rn(sum, t[w & 0xffu]);
+            sum = __fadd_rn(sum, t[256 + ((w >> 8) & 0xffu)]);
+            sum = __fadd_rn(sum, t[512 + ((w >> 16) & 0xffu)]);
+            sum = __fadd_rn(sum, t[768 + (w >> 24)]);
+        }
+        r.sum = sum;
+    }
+}
+
+template <int CS> __device__ __forceinline__ float code_sum(const float *s_lut, const CodeRegs<CS> &r)
+{
+    if constexpr (CS > 0)
+        return adc_sum<CS>(s_lut, r.w);
+    else
+        return r.sum;
+}
+
 } // namespace ivfhnsw_gpu_impl

@@ -125,6 +125,7 @@ void IndexIVF_HNSW::device_upload_common()
     desc.opq_A = do_opq ? opq_matrix->A.data() : nullptr;
     desc.shard_rank = 0;
     desc.shard_world = 1;
+    desc.list_owner = nullptr;
     if (pq->centroids.size() != 256 * d || norm_pq->centroids.size() != 256)
         throw std::runtime_error("IndexIVF_HNSW: pq / norm_pq have unexpected shapes");
     if (ivfhnsw_gpu_upload_ivf(gpu_, &desc))
@@ -219,7 +220,29 @@ void IndexIVF_HNSW::search(size_t k, const float *x, float *distances, long *lab
 
 void IndexIVF_HNSW::search_debug(size_t k, const float *x, float *distances, long *labels)
 {
-    search(k, x, distances, labels);
+    // search() plus the coarse-stage report of IndexIVF_HNSW.cpp:343-353: the walk runs once, its result is printed
+    // (farthest probe first, as the reference loops) and handed to the scan
+    ensure_device();
+    std::vector<float> xr(d);
+    const float *q = x;
+    if (do_opq) {
+        opq_matrix->apply_noalloc(1, x, xr.data());
+        q = xr.data();
+    }
+    std::vector<idx_t> cid(nprobe);
+    std::vector<float> cd(nprobe);
+    if (ivfhnsw_gpu_coarse(gpu_, 1, q, nprobe, quantizer->efSearch, cid.data(), cd.data()))
+        gpu_fail("ivfhnsw_gpu_coarse");
+    std::cout << "coarse centroids info:" << std::endl;
+    for (size_t i = nprobe; i-- > 0;) {
+        if (cid[i] >= nc)
+            continue; // the walk found fewer than nprobe centroids (undefined in the reference)
+        std::cout << "centroid " << cid[i] << " with query distance of " << cd[i] << std::endl;
+        std::cout << "group size: " << norm_codes[cid[i]].size() << std::endl;
+    }
+    ivfhnsw_search_params p = {nprobe, max_codes, quantizer->efSearch, 0, 1};
+    if (ivfhnsw_gpu_search(gpu_, 1, k, x, cid.data(), cd.data(), &p, distances, reinterpret_cast<int64_t *>(labels)))
+        gpu_fail("ivfhnsw_gpu_search");
 }
 
 IndexIVF_HNSW::idx_t IndexIVF_HNSW::search_enn(const float *x, float *distances, long *labels)

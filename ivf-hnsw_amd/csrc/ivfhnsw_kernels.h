@@ -32,11 +32,16 @@ constexpr uint32_t kOrdFltMax = 0x7f7fffffu | 0x80000000u; // orderable(FLT_MAX)
 constexpr uint64_t kKeyInit = (uint64_t)kOrdFltMax << 32;  // accept iff key < kKeyInit
 constexpr uint64_t kSignFlip = 0x8000000000000000ull;      // keys leave the library as signed-orderable int64
 
+constexpr uint32_t kNotOwned = 0xffffffffu;
+// dynamic LDS the run-time-code-size scan kernels may ask for (1 KB per code byte; the rest of the 160 KB holds
+// the plan chunk, the norm table and the top-k buffers)
+constexpr size_t kScanDynLdsMax = 128 * 1024;
+
 struct IvfTables {
     int d, M, dsub;             // M == code_size
     uint32_t nc;
     const uint64_t *goff;       // [nc+1] global list offsets
-    const uint32_t *loff;       // [nc] first local code of list c (undefined when not owned)
+    const uint32_t *loff;       // [nc] first local code of list c; kNotOwned when the list lives on another shard
     const float *centroid_norms;
     const float *pq_centroids;  // [M][256][dsub]
     const float *norm_table;    // [256]

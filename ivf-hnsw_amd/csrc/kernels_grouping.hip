@@ -127,7 +127,8 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
         const float alpha = g.alphas[c];
         const float oma = __fsub_rn(1.0f, alpha);
         const float term1 = __fmul_rn(oma, __fsub_rn(qd[i], t.centroid_norms[c]));
-        const bool owned = (c % t.shard_world) == t.shard_rank;
+        const uint32_t lo_c = t.loff[c];
+        const bool owned = lo_c != kNotOwned;
         uint32_t list_off = 0; // codes of this list before the current chunk of sub-groups
         for (int s0 = 0; s0 < nsubc; s0 += 64) {
             const int subc = s0 + lane;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
             const uint32_t rank_sc = __popcll(m & ((1ull << lane) - 1ull));
             if (scanned && owned) {
                 Seg sg;
-                sg.start = t.loff[c] + list_off + (in_sz - sz);
+                sg.start = lo_c + list_off + (in_sz - sz);
                 sg.len = sz;
                 sg.vpos = (uint32_t)ncode + (in_sc - sz);
                 sg.cterm = cterm;

@@ -234,13 +234,14 @@ __global__ __launch_bounds__(256) void plan_ivf_kernel(IvfTables t, const uint32
         const unsigned long long excl = incl - n;
         // the check follows the scoring (IndexIVF_HNSW.cpp:290-292): the first non-empty list is always scored
         const bool take = n != 0 && (excl < max_codes || excl == 0);
-        const bool owned = take && (c % t.shard_world == t.shard_rank);
+        const uint32_t lo_c = take ? t.loff[c] : kNotOwned;
+        const bool owned = lo_c != kNotOwned;
         const unsigned long long om = __ballot(owned);
         const unsigned long long own_incl = wave_incl_scan_u64(owned ? n : 0ull, lane);
         if (owned) {
             const uint32_t r = ns + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
             Seg sg;
-            sg.start = t.loff[c];
+            sg.start = lo_c;
             sg.len = (uint32_t)n;
             sg.vpos = (uint32_t)excl;
             sg.cterm = __fsub_rn(cd[(size_t)q * nprobe + i], t.centroid_norms[c]);
@@ -313,7 +314,7 @@ template <int REP> __device__ __forceinline__ uint32_t lut_byte_offset(uint32_t 
 }
 
 template <int CS, int REP>
-__device__ __forceinline__ float adc_sum_rep(const float *s_lut, const uint32_t (&w)[CS / 4], uint32_t rbase)
+__device__ __forceinline__ float adc_sum_rep(const float *s_lut, const uint32_t (&w)[CS > 0 ? CS / 4 : 1], uint32_t rbase)
 {
     float sum = 0.0f;
     const char *base = reinterpret_cast<const char *>(s_lut);
@@ -333,9 +334,13 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                                                           const Seg *__restrict__ segs,
                                                           const uint32_t *__restrict__ lpos,
                                                           const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                          unsigned long long *__restrict__ keys)
+                                                          unsigned long long *__restrict__ keys, int cs_rt)
 {
-    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256 * REP];
+    // CS == 0: run-time code size cs_rt, table in dynamic LDS (code sizes without an instantiation of their own)
+    __shared__ __attribute__((aligned(16))) float s_lut_fixed[(CS > 0 ? CS : 1) * 256 * REP];
+    extern __shared__ __attribute__((aligned(16))) float s_lut_dyn[];
+    float *s_lut = CS > 0 ? s_lut_fixed : s_lut_dyn;
+    const int csz = CS > 0 ? CS : cs_rt;
     __shared__ float s_norm[256];
     __shared__ __attribute__((aligned(16))) Seg s_seg[SEGCAP];
     __shared__ uint32_t s_lpos[SEGCAP + 1];
@@ -356,10 +361,10 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
         return;
 
     {
-        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
+        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * csz * 256);
         if constexpr (REP == 1) {
             float4 *dst = reinterpret_cast<float4 *>(s_lut);
-            for (int i = tid; i < CS * 64; i += THREADS)
+            for (int i = tid; i < csz * 64; i += THREADS)
                 dst[i] = src[i];
         } else {
             constexpr int G = 32 / REP; // dwords of one copy inside a 32-dword bank row
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
         uint32_t seg_lo = 0, seg_hi = 0, seg_start = 0, seg_vpos = 0;
         float seg_ct = 0.f;
         for (uint32_t base = b0; base < b1; base += THREADS * U) {
-            uint32_t w[U][CS / 4];
+            CodeRegs<CS> w[U];
             uint32_t nb[U], vp[U];
             float ct[U];
             bool ok[U];
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                     }
                     const uint32_t off = p - seg_lo;
                     const uint32_t gi = seg_start + off;
-                    load_code_words<CS>(codes, gi, w[u]);
+                    code_fetch<CS>(codes, gi, cs_rt, s_lut, w[u]);
                     nb[u] = norm_codes[gi];
                     vp[u] = seg_vpos + off;
                     ct[u] = seg_ct;
@@ -460,7 +465,11 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (ok[u]) {
-                    const float sum = adc_sum_rep<CS, REP>(s_lut, w[u], rbase);
+                    float sum;
+                    if constexpr (CS > 0)
+                        sum = adc_sum_rep<CS, REP>(s_lut, w[u].w, rbase);
+                    else
+                        sum = w[u].sum;
                     const float tt = __fadd_rn(ct[u], s_norm[nb[u]]);
                     const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
                     if (dist < FLT_MAX) { // also rejects NaN, as 'dist < distances[0]' does
@@ -621,7 +630,7 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
     }
 #define IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, UU)                                                                     \
     hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, UU, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
-                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64)
+                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, t.M)
 #define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                 \
     do {                                                   \
         if (unroll == 2)                                   \
@@ -673,7 +682,23 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
     case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
     case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
     case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
-    default: return hipErrorInvalidValue;
+    default: {
+        // any other multiple of 4 (IndexIVF_HNSW.cpp:805): the run-time form, table in dynamic LDS
+        const size_t shm = (size_t)t.M * 1024;
+        if (t.M % 4 || shm > kScanDynLdsMax)
+            return hipErrorInvalidValue;
+        auto *kern = scan_k1_kernel<0, 256, 2, 1, 256>;
+        static size_t attr_set = 0;
+        if (shm > attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess)
+                return e;
+            attr_set = shm;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nq * nsplit), dim3(256), shm, s, t.codes, t.norm_codes, luts, t.norm_table,
+                           segs, lpos, hdr, max_seg, nsplit, reinterpret_cast<unsigned long long *>(keys), t.M);
+        return hipGetLastError();
+    }
     }
 }
 
@@ -793,9 +818,11 @@ __global__ void fill_lists_kernel(IvfTables t, uint8_t *__restrict__ codes, uint
                                   unsigned long long seed_norms)
 {
     const int cs4 = t.M / 4; // dwords per code
-    for (uint32_t c = t.shard_rank + blockIdx.x * t.shard_world; c < t.nc; c += gridDim.x * t.shard_world) {
-        const unsigned long long g0 = t.goff[c], n = t.goff[c + 1] - g0;
+    for (uint32_t c = blockIdx.x; c < t.nc; c += gridDim.x) {
         const uint32_t l0 = t.loff[c];
+        if (l0 == kNotOwned)
+            continue;
+        const unsigned long long g0 = t.goff[c], n = t.goff[c + 1] - g0;
         uint32_t *dst = reinterpret_cast<uint32_t *>(codes + (size_t)l0 * t.M);
         for (unsigned long long j = threadIdx.x; j < n * cs4; j += blockDim.x) {
             const unsigned long long k = g0 * cs4 + j; // global dword index of the code stream

@@ -51,9 +51,14 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
                                                         const PlanHdr *__restrict__ hdr, int max_seg, int k,
                                                         unsigned long long *__restrict__ keys,
                                                         unsigned long long *__restrict__ stream,
-                                                        uint32_t *__restrict__ stream_len, uint32_t stream_cap)
+                                                        uint32_t *__restrict__ stream_len, uint32_t stream_cap,
+                                                        int cs_rt)
 {
-    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
+    // CS == 0: run-time code size cs_rt, table in dynamic LDS (see scan_k1_kernel)
+    __shared__ __attribute__((aligned(16))) float s_lut_fixed[(CS > 0 ? CS : 1) * 256];
+    extern __shared__ __attribute__((aligned(16))) float s_lut_dyn[];
+    float *s_lut = CS > 0 ? s_lut_fixed : s_lut_dyn;
+    const int csz = CS > 0 ? CS : cs_rt;
     __shared__ float s_norm[256];
     __shared__ __attribute__((aligned(16))) Seg s_seg[TK_SEGCAP];
     __shared__ uint32_t s_lpos[TK_SEGCAP + 1];
@@ -70,11 +75,16 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
         return; // keys were reset by the plan kernel
     }
     {
-        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
+        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * csz * 256);
         float4 *dst = reinterpret_cast<float4 *>(s_lut);
+        if constexpr (CS > 0) {
 #pragma unroll
-        for (int i = 0; i < CS * 64 / 256; i++)
-            dst[i * 256 + tid] = src[i * 256 + tid];
+            for (int i = 0; i < CS * 64 / 256; i++)
+                dst[i * 256 + tid] = src[i * 256 + tid];
+        } else {
+            for (int i = tid; i < csz * 64; i += 256)
+                dst[i] = src[i];
+        }
         s_norm[tid] = norm_table[tid];
         for (int i = tid; i < TK_N; i += 256)
             s_buf[i] = ~0ull;
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
             const int u_now = T == kKeyInit ? 1 : TK_U;
             unsigned long long key[TK_U];
             bool pass[TK_U];
-            uint32_t w[TK_U][CS / 4], nbv[TK_U], vp[TK_U];
+            CodeRegs<CS> w[TK_U];
+            uint32_t nbv[TK_U], vp[TK_U];
             float ct[TK_U];
             bool ok[TK_U];
 #pragma unroll
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
                     }
                     const uint32_t off = p - seg_lo;
                     const uint32_t gi = seg_start + off;
-                    load_code_words<CS>(codes, gi, w[u]);
+                    code_fetch<CS>(codes, gi, cs_rt, s_lut, w[u]);
                     nbv[u] = norm_codes[gi];
                     vp[u] = seg_vpos + off;
                     ct[u] = seg_ct;
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const uint8_t *__restric
                 pass[u] = false;
                 key[u] = 0;
                 if (ok[u]) {
-                    const float sum = adc_sum<CS>(s_lut, w[u]);
+                    const float sum = code_sum<CS>(s_lut, w[u]);
                     const float tt = __fadd_rn(ct[u], s_norm[nbv[u]]);
                     const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
                     if (dist < FLT_MAX) {
@@ -375,13 +386,28 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
 #define IVFHNSW_TOPK(CS)                                                                                              \
     hipLaunchKernelGGL((scan_topk_kernel<CS>), grid, block, 0, s, t.codes, t.norm_codes, luts, t.norm_table, segs, lpos, \
-                       hdr, max_seg, k, k64, reinterpret_cast<unsigned long long *>(stream), stream_len, stream_cap)
+                       hdr, max_seg, k, k64, reinterpret_cast<unsigned long long *>(stream), stream_len, stream_cap, t.M)
     switch (t.M) {
     case 4: IVFHNSW_TOPK(4); break;
     case 8: IVFHNSW_TOPK(8); break;
     case 16: IVFHNSW_TOPK(16); break;
     case 32: IVFHNSW_TOPK(32); break;
-    default: return hipErrorInvalidValue;
+    default: {
+        const size_t shm = (size_t)t.M * 1024;
+        if (t.M % 4 || shm > kScanDynLdsMax)
+            return hipErrorInvalidValue;
+        auto *kern = scan_topk_kernel<0>;
+        static size_t attr_set = 0;
+        if (shm > attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            if (e != hipSuccess)
+                return e;
+            attr_set = shm;
+        }
+        hipLaunchKernelGGL(kern, grid, block, shm, s, t.codes, t.norm_codes, luts, t.norm_table, segs, lpos, hdr, max_seg, k,
+                           k64, reinterpret_cast<unsigned long long *>(stream), stream_len, stream_cap, t.M);
+        break;
+    }
     }
 #undef IVFHNSW_TOPK
     return hipGetLastError();

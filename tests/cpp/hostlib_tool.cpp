@@ -8,6 +8,7 @@
 //   pq_roundtrip in out | vt_roundtrip in out
 //   search ivf|grouping d nc code_size nsubc centroids info edges pq norm_pq opq|- index queries.fvecs nq k nprobe
 //          max_codes efSearch pruning out.bin                        (GPU; single-query loop AND batch)
+//   siblings <same arguments>    (GPU; search_debug, search_enn, search2, search2m of IndexIVF_HNSW.cpp:328-534)
 #include <ivf-hnsw/IndexIVF_HNSW_Grouping.h>
 #include <ivf-hnsw/hnswalg.h>
 
@@ -231,7 +232,7 @@ static int run(int argc, char **argv)
         delete index;
         return 0;
     }
-    if (cmd == "search" && argc == 22) {
+    if ((cmd == "search" || cmd == "siblings") && argc == 22) {
         const bool grp = !strcmp(argv[2], "grouping");
         const size_t d = atol(argv[3]), nc = atol(argv[4]), cs = atol(argv[5]), nsubc = atol(argv[6]);
         const char *centroids = argv[7], *info = argv[8], *edges = argv[9], *ppq = argv[10], *pnorm = argv[11],
@@ -263,13 +264,62 @@ static int run(int argc, char **argv)
             std::ifstream in(pq_, std::ios::binary);
             readXvec<float>(in, q.data(), d, nq);
         }
-        // (1) one query per call, as the drivers do; (2) the batched extension.  Both are written out.
-        std::vector<float> dist(2 * nq * k);
-        std::vector<long> lab(2 * nq * k);
-        for (size_t i = 0; i < nq; i++)
-            index->search(k, q.data() + i * d, dist.data() + i * k, lab.data() + i * k);
-        index->search_batch(nq, k, q.data(), dist.data() + nq * k, lab.data() + nq * k);
-        dump(argv[21], lab.data(), lab.size() * sizeof(long), dist.data(), dist.size() * sizeof(float));
+        if (cmd == "search") {
+            // (1) one query per call, as the drivers do; (2) the batched extension.  Both are written out.
+            std::vector<float> dist(2 * nq * k);
+            std::vector<long> lab(2 * nq * k);
+            for (size_t i = 0; i < nq; i++)
+                index->search(k, q.data() + i * d, dist.data() + i * k, lab.data() + i * k);
+            index->search_batch(nq, k, q.data(), dist.data() + nq * k, lab.data() + nq * k);
+            dump(argv[21], lab.data(), lab.size() * sizeof(long), dist.data(), dist.size() * sizeof(float));
+        } else {
+            // The sibling entry points of IndexIVF_HNSW (IndexIVF_HNSW.cpp:328-534), one query per call as a driver
+            // would use them.  Output: labels [debug nq*k | enn nq | search2 nq*k | search2m nq*nprobe*k], then the
+            // distances in the same layout, then the centroid search_enn returned (u32 [nq]) and the coarse stage
+            // handed to search2 / search2m (ids u32 [nq*nprobe], dists f32 [nq*nprobe]).
+            const size_t n_lab = nq * k + nq + nq * k + nq * nprobe * k;
+            std::vector<long> lab(n_lab, -7);
+            std::vector<float> dist(n_lab, -7.f);
+            std::vector<uint32_t> enn_c(nq), cids(nq * nprobe);
+            std::vector<float> cds(nq * nprobe);
+            long *l_dbg = lab.data(), *l_enn = l_dbg + nq * k, *l_s2 = l_enn + nq, *l_s2m = l_s2 + nq * k;
+            float *d_dbg = dist.data(), *d_enn = d_dbg + nq * k, *d_s2 = d_enn + nq, *d_s2m = d_s2 + nq * k;
+            for (size_t i = 0; i < nq; i++) {
+                const float *x = q.data() + i * d;
+                index->search_debug(k, x, d_dbg + i * k, l_dbg + i * k);
+                enn_c[i] = index->search_enn(x, d_enn + i, l_enn + i);
+                // the caller's coarse stage of search2 / search2m: the host walk on the rotated query
+                // (IndexIVF_HNSW.cpp:240-259 is what a driver repeats before calling search2)
+                const float *xr = index->do_opq ? index->opq_matrix->apply(1, x) : x;
+                auto coarse = index->quantizer->searchKnn(xr, nprobe);
+                if (coarse.size() != nprobe)
+                    throw std::runtime_error("host walk returned fewer than nprobe centroids");
+                for (size_t j = nprobe; j-- > 0;) {
+                    cds[i * nprobe + j] = coarse.top().first;
+                    cids[i * nprobe + j] = coarse.top().second;
+                    coarse.pop();
+                }
+                if (index->do_opq)
+                    delete[] const_cast<float *>(xr);
+                index->search2(k, x, d_s2 + i * k, l_s2 + i * k, cds.data() + i * nprobe, cids.data() + i * nprobe);
+                std::vector<float *> dp(nprobe);
+                std::vector<long *> lp(nprobe);
+                for (size_t j = 0; j < nprobe; j++) {
+                    dp[j] = d_s2m + (i * nprobe + j) * k;
+                    lp[j] = l_s2m + (i * nprobe + j) * k;
+                }
+                index->search2m(k, x, dp.data(), lp.data(), cds.data() + i * nprobe, cids.data() + i * nprobe);
+            }
+            FILE *f = fopen(argv[21], "wb");
+            if (!f)
+                throw std::runtime_error("cannot write the result file");
+            fwrite(lab.data(), sizeof(long), lab.size(), f);
+            fwrite(dist.data(), sizeof(float), dist.size(), f);
+            fwrite(enn_c.data(), 4, enn_c.size(), f);
+            fwrite(cids.data(), 4, cids.size(), f);
+            fwrite(cds.data(), 4, cds.size(), f);
+            fclose(f);
+        }
         delete index;
         return 0;
     }

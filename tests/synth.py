@@ -279,11 +279,21 @@ def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=4096):
     return counts.astype(np.uint8), links
 
 
-def synthetic_codes_shard(seed, offsets, code_size, rank, world):
-    """The lists c % world == rank of the device's synthetic corpus (same bytes as the unsharded stream)."""
+def synthetic_codes_shard(seed, offsets, code_size, rank, world, list_owner=None):
+    """The lists a rank owns (list_owner[c] == rank, default c % world == rank) of the device's synthetic corpus
+    (same bytes as the unsharded stream): (global ids, codes, norm_codes) in increasing list order."""
+    nc = len(offsets) - 1
+    if list_owner is None:
+        owned = np.arange(rank, nc, world)
+    else:
+        owned = np.nonzero(np.asarray(list_owner) == rank)[0]
+    return synthetic_codes_lists(seed, offsets, code_size, owned)
+
+
+def synthetic_codes_lists(seed, offsets, code_size, lists):
+    """The given lists (increasing) of the device's synthetic corpus: (global vector index, codes, norm_codes)."""
     off = offsets.astype(np.int64)
-    nc = len(off) - 1
-    owned = np.arange(rank, nc, world)
+    owned = np.asarray(lists, np.int64)
     sizes = off[owned + 1] - off[owned]
     n = int(sizes.sum())
     # global vector index of every owned vector
@@ -306,6 +316,25 @@ def synthetic_codes_shard(seed, offsets, code_size, rank, world):
         v = _mix64(nseed + (w + np.uint64(1)) * GOLDEN)
         norm_codes = ((v >> ((gidx % np.uint64(8)) * np.uint64(8))) & np.uint64(0xff)).astype(np.uint8)
     return gidx.astype(np.uint32), np.ascontiguousarray(codes), norm_codes
+
+
+def synthetic_codes_sparse(seed, offsets, code_size, lists=None, into=None):
+    """A full-size host view of the device's synthetic corpus in which only `lists` hold their real bytes -- for an
+    oracle sample at sizes (1B vectors = 21 GB) whose full host copy would take most of a minute.  The arrays come from
+    calloc, so the lists never touched stay uncommitted zero pages.  `into` = a previous result to fill further."""
+    n = int(offsets[-1])
+    if into is None:
+        into = (np.zeros(n, np.uint32), np.zeros((n, code_size), np.uint8), np.zeros(n, np.uint8))
+    ids, codes, norm_codes = into
+    if lists is not None and len(lists):
+        lists = np.unique(np.asarray(lists, np.int64))
+        for a in range(0, len(lists), 8192):  # bounded temporaries
+            gidx, c, nc_ = synthetic_codes_lists(seed, offsets, code_size, lists[a:a + 8192])
+            g = gidx.astype(np.int64)
+            ids[g] = gidx
+            codes[g] = c
+            norm_codes[g] = nc_
+    return into
 
 
 def knn_ids_torch(centroids, k, device=None, chunk=4096):

@@ -160,6 +160,54 @@ def test_class_search_k10_returns_the_reference_heap_array(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("opq,k", [(False, 1), (True, 1), (False, 5)])
+def test_class_sibling_entry_points_equal_oracle(tmp_path, opq, k):
+    """search_debug, search_enn, search2 and search2m (IndexIVF_HNSW.cpp:328-534) through the class surface.
+    search_debug == search; search_enn == the search with nprobe 1 and k 1; search2 == the search on the caller's
+    coarse stage (here the HOST walk of the class's quantizer, which must equal the oracle's walk); search2m == one
+    heap per probe, each list alone (the reference compares against heap 0 from racing OpenMP threads,
+    IndexIVF_HNSW.cpp:523 -- undefined; the per-probe result is the defined part)."""
+    c = synth.make_corpus(seed=75, nc=128, d=128, M=16, n_base=8000, nq=24, efConstruction=80, opq=opq)
+    nprobe, max_codes, ef = 6, 1200, 32
+    nq = len(c["queries"])
+    p = hostio.dump_corpus(c, str(tmp_path))
+    out = str(tmp_path / "sib.bin")
+    tool("siblings", "ivf", c["d"], c["nc"], c["code_size"], 0, p["centroids"], p["info"], p["edges"], p["pq"],
+         p["norm_pq"], p["opq"], p["index"], p["queries"], nq, k, nprobe, max_codes, ef, 0, out)
+    raw = np.fromfile(out, np.uint8)
+    n_lab = nq * k + nq + nq * k + nq * nprobe * k
+    lab = raw[:n_lab * 8].view(np.int64)
+    dist = raw[n_lab * 8:n_lab * 12].view(np.float32)
+    rest = raw[n_lab * 12:]
+    enn_c = rest[:nq * 4].view(np.uint32)
+    cids = rest[nq * 4:nq * 4 + nq * nprobe * 4].view(np.uint32).reshape(nq, nprobe)
+    cds = rest[nq * 4 + nq * nprobe * 4:].view(np.float32).reshape(nq, nprobe)
+
+    def cut(a):
+        o = [0, nq * k, nq * k + nq, 2 * nq * k + nq, n_lab]
+        return (a[o[0]:o[1]].reshape(nq, k), a[o[1]:o[2]].reshape(nq, 1), a[o[2]:o[3]].reshape(nq, k),
+                a[o[3]:o[4]].reshape(nq, nprobe, k))
+
+    l_dbg, l_enn, l_s2, l_s2m = cut(lab)
+    d_dbg, d_enn, d_s2, d_s2m = cut(dist)
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef)
+    ref_d, ref_l, ref_cid, ref_cd, _ = ox.search_batch(c["queries"], k=k)
+    same = lambda a, b: np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+    assert np.array_equal(l_dbg, ref_l) and same(d_dbg, ref_d)
+    assert np.array_equal(cids, ref_cid) and same(cds, ref_cd)      # the host walk of the class == the oracle's
+    assert np.array_equal(l_s2, ref_l) and same(d_s2, ref_d)
+    ox.set_params(1, max_codes, ef)
+    e_d, e_l, e_cid, _, _ = ox.search_batch(c["queries"], k=1)
+    assert np.array_equal(l_enn, e_l) and same(d_enn, e_d) and np.array_equal(enn_c, e_cid[:, 0])
+    ox.set_params(1, 2 ** 62, ef)
+    for i in range(nq):
+        for j in range(nprobe):
+            pd, pl, _ = ox.search_coarse(c["queries"][i], ref_cid[i, j:j + 1], ref_cd[i, j:j + 1], k=k)
+            assert np.array_equal(l_s2m[i, j], pl) and same(d_s2m[i, j], pd)
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_DRV, "test_ivfhnsw_deep1b")),
                     reason="reference drivers not built (make -C oracle ref_drivers needs /root/reference)")
 @pytest.mark.parametrize("driver,opq", [("test_ivfhnsw_deep1b", False), ("test_ivfhnsw_deep1b", True),
