@@ -221,6 +221,9 @@ int ivfhnsw_gpu_reset_stage_ms(ivfhnsw_gpu *h);
 /* Accounting of the last search on this handle: codes scored by this shard (the reference's `ncode`,
  * IndexIVF_HNSW.cpp:290, summed over the batch) and (sub)lists scored.  Synchronises. */
 int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nsegments);
+/* Name of the scan kernel the last search on this handle launched (the dominant kernel of the path: bench.py
+ * reports its roofline under this name).  Never NULL; empty before the first search. */
+const char *ivfhnsw_gpu_last_scan_kernel(ivfhnsw_gpu *h);
 /* Bytes of HBM currently held by the handle. */
 int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes);
 

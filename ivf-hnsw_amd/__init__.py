@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_resolve_keys_dev", "ivfhnsw_gpu_coarse_dev", "ivfhnsw_gpu_coarse", "ivfhnsw_gpu_set_profiling",
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
-    "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev",
+    "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
 )
 
 
@@ -97,6 +97,8 @@ def lib():
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_memory_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
+        L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -319,6 +321,9 @@ class GpuIndex:
         a, b = C.c_uint64(), C.c_uint64()
         _check(lib().ivfhnsw_gpu_last_scan_counts(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_scan_kernel(self):
+        return lib().ivfhnsw_gpu_last_scan_kernel(self._h).decode()
 
     def memory_bytes(self):
         a = C.c_uint64()

@@ -102,6 +102,7 @@ struct ivfhnsw_gpu {
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
 
     int last_nq = 0, last_max_seg = 0;
+    const char *last_scan_kernel = "";
 
     bool profiling = false;
     std::vector<StageEvent> pending;
@@ -1167,6 +1168,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
                             h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
                             heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
                             heap ? kHeapStreamCap : 0, seg_hint));
+        h->last_scan_kernel = last_scan_kernel_name();
     }
     // 6. select
     {
@@ -1300,6 +1302,8 @@ int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nse
         *nsegments = out[1];
     return IVFHNSW_OK;
 }
+
+const char *ivfhnsw_gpu_last_scan_kernel(ivfhnsw_gpu *h) { return h ? h->last_scan_kernel : ""; }
 
 int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
 {

@@ -100,6 +100,7 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys,
                        uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0,
                        int seg_len_hint = 0); // expected codes per plan segment (0 = unknown): picks the scan form
+const char *last_scan_kernel_name(); // the kernel the calling thread's last launch_scan chose
 // k > 1 in faiss heap-array order: sequential replay of the top-k kernel's candidate stream
 hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
                               const uint64_t *stream, const uint32_t *stream_len, uint32_t stream_cap, int nq, int k,

@@ -590,6 +590,10 @@ __global__ __launch_bounds__(256) void scan_k1_short_kernel(const uint8_t *__res
     }
 }
 
+// which scan kernel the last launch_scan of this thread chose (reported by bench.py next to its roofline)
+static thread_local const char *g_scan_kernel_name = "";
+const char *last_scan_kernel_name() { return g_scan_kernel_name; }
+
 // tuning knob for A/B runs on the device: IVFHNSW_SCAN_REP = 1, 2 or 4 (LDS copies of the table)
 static int scan_rep_choice()
 {
@@ -614,6 +618,7 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         return !(e && atoi(e) == 0);
     }();
     if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
+        g_scan_kernel_name = "scan_k1_short_kernel";
 #define IVFHNSW_SCAN_SHORT(GG)                                                                                        \
     hipLaunchKernelGGL((scan_k1_short_kernel<CS, GG>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table, \
                        segs, hdr, max_seg, nsplit, k64)
@@ -646,6 +651,7 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         return (v == 2 || v == 8) ? v : 4;
     }();
     const int rep = CS <= 16 ? scan_rep_choice() : 1;
+    g_scan_kernel_name = "scan_k1_kernel";
     if (max_seg <= 64) {
         if (rep == 4)
             IVFHNSW_SCAN(64, 4, 512);
@@ -675,8 +681,10 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
 {
     if (nq == 0)
         return hipSuccess;
-    if (k != 1)
+    if (k != 1) {
+        g_scan_kernel_name = "scan_topk_kernel";
         return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys, stream, stream_len, stream_cap);
+    }
     switch (t.M) {
     case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
     case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
@@ -687,6 +695,7 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
         const size_t shm = (size_t)t.M * 1024;
         if (t.M % 4 || shm > kScanDynLdsMax)
             return hipErrorInvalidValue;
+        g_scan_kernel_name = "scan_k1_kernel (run-time code size)";
         auto *kern = scan_k1_kernel<0, 256, 2, 1, 256>;
         static size_t attr_set = 0;
         if (shm > attr_set) {

@@ -47,12 +47,50 @@ def query_slice(nq, rank, world):
     return min(rank * per, nq), min((rank + 1) * per, nq), per
 
 
-def merge_keys_labels(keys, labels_of_owner, group=None):
-    """The exchange step on tensors of any device: in-place MIN of the signed keys; returns nothing.
-    `labels_of_owner` must already hold -1 wherever this rank does not own the (pre-merge) winner; it is
-    MAX-reduced after the caller re-resolved it against the merged keys."""
-    import torch.distributed as dist
-    dist.all_reduce(keys, op=dist.ReduceOp.MIN, group=group)
+def partition_lists(centroids, list_sizes, world, method="spatial"):
+    """Owner table for list-wise sharding (ivfhnsw_ivf_desc.list_owner): rank of every inverted list.
+
+    "spatial": recursive bisection of the centroids along their principal direction, each cut placed so that both
+    sides hold the same number of CODES per rank (any world size: a node of w ranks splits w//2 : w - w//2).  Lists
+    whose centroids are close end up on the same rank, so a query's probes -- the centroids nearest to it -- fall
+    on few ranks; only those build and stage the query's table (the plan of every other rank is empty for it).
+    How much that buys depends on the data: clustered descriptors (SIFT, DEEP) concentrate a query's probes,
+    iid-Gaussian synthetic centroids in 128 dimensions hardly do (DESIGN.md 7 has the measured figures).
+    "mod": c % world, the layout of the C ABI's default."""
+    nc = len(list_sizes)
+    if world == 1:
+        return np.zeros(nc, np.uint32)
+    if method == "mod":
+        return (np.arange(nc, dtype=np.uint64) % np.uint64(world)).astype(np.uint32)
+    if method != "spatial":
+        raise ValueError("unknown partition method %r" % (method,))
+    x_all = np.ascontiguousarray(centroids, np.float32)
+    sizes = np.asarray(list_sizes, np.float64)
+    owner = np.zeros(nc, np.uint32)
+    work = [(np.arange(nc, dtype=np.int64), 0, world)]
+    while work:
+        idx, r0, w = work.pop()
+        if w == 1 or len(idx) == 0:
+            owner[idx] = r0
+            continue
+        wl = w // 2
+        x = x_all[idx].astype(np.float64)
+        x -= x.mean(0)
+        v = np.ones(x.shape[1]) / np.sqrt(x.shape[1])     # power iteration from a fixed start: deterministic
+        for _ in range(12):
+            v = x.T @ (x @ v)
+            n = np.linalg.norm(v)
+            if n == 0:
+                v = np.ones(x.shape[1]) / np.sqrt(x.shape[1])
+                break
+            v /= n
+        order = np.argsort(x @ v, kind="stable")
+        cs = np.cumsum(sizes[idx][order] + 1e-9)          # the epsilon orders empty lists too
+        cut = int(np.searchsorted(cs, cs[-1] * wl / w))
+        cut = min(max(cut, 1), len(idx) - 1) if len(idx) > 1 else 0
+        work.append((idx[order[:cut]], r0, wl))
+        work.append((idx[order[cut:]], r0 + wl, w - wl))
+    return owner
 
 
 def _all_gather_rows(buf, rank, per, group):
