@@ -4,21 +4,25 @@
 One "step" = one pass of the whole hot path (rotate -> HNSW coarse walk -> PQ inner-product table ->
 scan plan -> ADC list scan -> top-1 select) over one batch of queries that is already resident in HBM.
 
-Workload (BASELINE.json configs[1]): synthetic 100M x 128-d, 2^17 centroids, PQ16, nprobe 32, 10 k-query
-batch, at the paper operating point (nprobe, max_codes, efSearch) = (32, 10000, 80)
-(reference examples/run_sift1b.sh:37-43).  SIFT1B-shaped synthetic data: see tests/synth.py.
+Default workload = the shape BASELINE.json's metric is quoted on ("SIFT1B PQ16 nprobe=32"): synthetic
+1B x 128-d, the reference's 993 127 centroids, PQ16, at the paper operating point (nprobe, max_codes, efSearch) =
+(32, 10000, 80) (reference examples/run_sift1b.sh:37-43), batch 10 k.  It fits ONE GPU (26 GB).  SIFT1B-shaped
+synthetic data: see tests/synth.py.  The same JSON line carries `secondary` results for configs[1] (100M, 2^17
+centroids) and configs[2] (the 1B corpus at (64, 30000, 100)).
 
-N > 1 (WEAK scaling): the per-GPU work is fixed -- every GPU holds 100M codes and walks 10 k
-queries -- so N GPUs search an N x 100M corpus with N x 2^17 centroids for N x 10 k queries per step (N = 8:
-800M vectors, 2^20 centroids: the SIFT1B shape of BASELINE.json configs[3]/[4]).  The inverted lists are sharded
-list-wise over the ranks (c % N == rank), every rank holds the replicated tables and graph; the coarse walk is
-split over the ranks by query and all-gathered, every rank scans its shard for ALL queries, and the packed
-(distance, scan position) keys are MIN-all-reduced over RCCL, labels MAX-all-reduced.
+N > 1: the SAME 1B corpus, its inverted lists sharded list-wise over the N ranks by an owner table
+(a balanced spatial partition of the centroids, ivf-hnsw_amd/distributed.py); every rank holds the replicated
+tables and graph.  The coarse walk is split over the ranks by query and all-gathered, every rank scans the lists
+it owns for ALL queries, and the packed (distance, scan position) keys are MIN-all-reduced over RCCL, the owner's
+labels MAX-all-reduced.
+  --scaling weak   (default): N x 10 k queries per step -- per-GPU work fixed (10 k walks, 1/N of N x the scan).
+  --scaling strong           : 80 k queries per step at every N -- total work fixed.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,6 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak (spec)
+METRIC = "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak"
 
 WORKLOADS = {
     # name: (n_total, nc, d, M, nprobe, max_codes, efSearch, nq)
@@ -39,22 +44,122 @@ WORKLOADS = {
     # Grouping + Pruning + OPQ at the reference's preset (examples/run_sift1b_grouping_OPQ.sh:7-53): nsubc 64
     "grouping-100M-pq16-nc131072-nsubc64-opq-pruning": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
     "grouping-10M-pq16-nc16384-nsubc64-opq-pruning": (10_000_000, 1 << 14, 128, 16, 32, 10000, 80, 10000),
-    # ... and at the reference's full size (BASELINE.json configs[3]) on ONE GPU; --no-cpu-baseline as for the 1B
-    # shapes below (their CPU leg builds a 21-GB host copy of the lists: fine on the GPU box, not in a small container)
+    # ... and at the reference's full size (BASELINE.json configs[3]) on ONE GPU
     "grouping-1B-pq16-nc993127-nsubc64-opq-pruning": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
-    # The 1B shapes of BASELINE.json configs[2] and [4] on ONE GPU (21 GB of lists; the CPU leg builds a host copy
-    # of them -- pass --no-cpu-baseline where 25 GB of host memory are not to spare).  Parameters:
+    # The 1B shapes of the metric line, configs[2] and configs[4] on ONE GPU (21 GB of lists; the CPU leg builds a
+    # host copy of them -- pass --no-cpu-baseline where 25 GB of host memory are not to spare).  Parameters:
     # examples/run_sift1b.sh:37-43 (the two paper points) and examples/run_deep1b_OPQ.sh.
     "synthetic-1B-pq16-nc993127-nprobe32": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
     "synthetic-1B-pq16-nc993127-nprobe64": (1_000_000_000, 993127, 128, 16, 64, 30000, 100, 10000),
     "deep-1B-d96-opq-pq16-nc999973-nprobe128": (1_000_000_000, 999973, 96, 16, 128, 100000, 130, 10000),
 }
 WORKLOAD_FLAGS = {"deep-1B-d96-opq-pq16-nc999973-nprobe128": {"kind": "deep", "opq": True}}
-DEFAULT_WORKLOAD = "synthetic-100M-pq16-nc131072-nprobe32"
+DEFAULT_WORKLOAD = "synthetic-1B-pq16-nc993127-nprobe32"
+STRONG_BATCH = 80000
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+class Corpus:
+    """Synthetic tables + graph of one workload and its device index (this rank's shard)."""
+
+    def __init__(self, pkg, synth, name, seed, dev, local_rank, rank=0, world=1, scale=1, partition="spatial", pkg_dist=None):
+        n_total, nc, d, M, self.nprobe, self.max_codes, self.ef, self.nq = WORKLOADS[name]
+        n_total, nc = n_total * scale, nc * scale
+        if n_total >= 2 ** 32:
+            raise SystemExit("corpus of %d vectors does not fit uint32 ids" % n_total)
+        self.name, self.n_total, self.nc, self.d, self.M, self.seed = name, n_total, nc, d, M, seed
+        flags = WORKLOAD_FLAGS.get(name, {})
+        self.kind = flags.get("kind", "sift")
+        self.grouping = name.startswith("grouping")
+        t0 = time.time()
+        self.tb = tb = synth.make_throughput_tables(seed, nc, d, M, n_total, kind=self.kind)
+        self.counts, self.links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
+        self.centroid_norms = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
+        self.opq_A, self.gt, self.vectors = None, None, tb["centroids"]
+        if flags.get("opq") and not self.grouping:
+            # OPQ: the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800);
+            # for a throughput corpus the synthetic centroids simply ARE the rotated ones
+            self.opq_A = synth.random_rotation(np.random.default_rng(seed + 4), d)
+        if self.grouping:
+            self.gt = synth.make_grouping_tables(seed + 3, tb, 64, device=dev)
+            self.opq_A = synth.random_rotation(np.random.default_rng(seed + 4), d)
+            self.vectors = synth.rotated_vectors(tb["centroids"], self.opq_A)
+        t_tab = time.time() - t0
+        self.owner = None
+        if world > 1:
+            sizes = np.diff(tb["offsets"].astype(np.int64))
+            self.owner = pkg_dist.partition_lists(tb["centroids"], sizes, world, partition)
+        self.code_seed = seed + 7
+        t0 = time.time()
+        self.g = g = pkg.GpuIndex(local_rank)
+        g.upload_ivf_synthetic(d, M, tb["offsets"], self.centroid_norms, tb["pq_centroids"], tb["norm_table"],
+                               self.code_seed, opq_A=self.opq_A, shard_rank=rank, shard_world=world,
+                               list_owner=self.owner)
+        g.upload_quantizer(self.counts, self.links, self.vectors, 0)
+        if self.grouping:
+            g.upload_grouping(64, self.gt["alphas"], self.gt["nn_centroid_idxs"], self.gt["subgroup_sizes"],
+                              self.gt["inter_centroid_dists"])
+        if rank == 0:
+            log("[bench] %s: tables + graph %.1fs (avg degree %.1f), on device %.1fs, %.2f GB held"
+                % (name, t_tab, self.counts.mean(), time.time() - t0, g.memory_bytes() / 1e9))
+
+    def queries(self, nq, seed):
+        rng = np.random.default_rng(seed)
+        # points near centroids, so that walks end in populated regions
+        return (self.tb["centroids"][rng.choice(self.nc, nq)]
+                + rng.normal(0, 12.0 if self.kind == "sift" else 0.03, size=(nq, self.d))).astype(np.float32)
+
+    def oracle(self, synth, orc):
+        """The CPU port over a full host copy of the device's byte stream (the cpu_baseline / parity leg only)."""
+        ids_h, codes_h, ncodes_h = synth.synthetic_codes(self.code_seed, self.tb["offsets"], self.M)
+        graph = orc.Hnsw.from_arrays(self.counts, self.links, self.vectors, 16, 0)
+        kw = {}
+        if self.grouping:
+            kw = dict(nsubc=64, alphas=self.gt["alphas"], nn_centroid_idxs=self.gt["nn_centroid_idxs"],
+                      subgroup_sizes=self.gt["subgroup_sizes"], inter_centroid_dists=self.gt["inter_centroid_dists"])
+        return orc.Index(self.d, self.M, graph, self.tb["pq_centroids"], self.tb["norm_table"], self.tb["offsets"],
+                         ids_h, codes_h, ncodes_h, self.centroid_norms, opq_A=self.opq_A, **kw)
+
+
+def timed_steps(torch, step, barrier, n):
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def scan_roofline(g, M, stage, traffic_gb):
+    """`roofline` of the dominant kernel: algorithmic bytes (code_size + 1 per scored code) per launch
+    over the kernel's average launch time (HIP events the library records around that launch on its stream)."""
+    ncodes, _ = g.last_scan_counts()
+    scan_ms, scan_n = stage["scan"]
+    avg_ms = scan_ms / max(1, scan_n)
+    bpc = M + 1
+    achieved = bpc * ncodes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": g.last_scan_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_gb,
+        "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/scan_traffic.json)",
+        "algorithmic_gb_per_launch": round(bpc * ncodes / 1e9, 4), "bytes_per_code": bpc, "codes_per_launch": ncodes,
+        "avg_launch_ms": round(avg_ms, 4),
+    }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch measured by the rocprofv3 PMC passes committed under profiles/ (bench.py cannot collect
+    counters itself); only reported for the workload they were taken on."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
+        e = tj.get("workloads", {}).get(workload)
+        if e:
+            return round(e["bytes_per_launch"] / 1e9, 4), round(e["walk_bytes_per_launch"] / 1e9, 4)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def main():
@@ -65,10 +170,16 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scale", type=int, default=0,
-                    help="corpus / centroid / batch multiplier; default = number of GPUs (weak scaling)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
+                    help="N > 1: weak = N x 10 k queries per step (per-GPU work fixed); strong = 80 k queries at every N")
+    ap.add_argument("--batch", type=int, default=0, help="queries per step (overrides the workload's / the scaling mode's)")
+    ap.add_argument("--partition", choices=("spatial", "mod"), default="spatial", help="owner table of the list shards")
+    ap.add_argument("--scale", type=int, default=1,
+                    help="legacy weak scaling: corpus and centroid multiplier (round 1 ran the 100M workload x N)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="batches in flight for the extra 'pipelined' figure (1 GPU only; 1 = skip it)")
+    ap.add_argument("--sustain-s", type=float, default=1.2, help="length of the extra sustained measurement, seconds")
     ap.add_argument("--dump", default=None, help="write rank 0's labels/distances of the last step to this .npz")
     args = ap.parse_args()
 
@@ -103,48 +214,19 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    n_total, nc, d, M, nprobe, max_codes, ef, nq = WORKLOADS[args.workload]
+    C = Corpus(pkg, synth, args.workload, args.seed, dev, local_rank, rank, world, args.scale, args.partition, pkg_dist)
+    g, d, M, nprobe, ef = C.g, C.d, C.M, C.nprobe, C.ef
+    max_codes = C.max_codes
     if os.environ.get("IVFHNSW_BENCH_MAX_CODES"):   # experiment knob: longer / shorter scans per query
         max_codes = int(os.environ["IVFHNSW_BENCH_MAX_CODES"])
-    scale = args.scale if args.scale > 0 else world
-    n_total, nc, nq = n_total * scale, nc * scale, nq * scale
-    if n_total >= 2 ** 32:
-        raise SystemExit("corpus of %d vectors does not fit uint32 ids" % n_total)
-    t0 = time.time()
-    flags = WORKLOAD_FLAGS.get(args.workload, {})
-    kind = flags.get("kind", "sift")
-    tb = synth.make_throughput_tables(args.seed, nc, d, M, n_total, kind=kind)
-    rng = np.random.default_rng(args.seed + 1)
-    # queries: points near centroids, so that walks end in populated regions
-    queries = (tb["centroids"][rng.choice(nc, nq)]
-               + rng.normal(0, 12.0 if kind == "sift" else 0.03, size=(nq, d))).astype(np.float32)
-    counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
-    centroid_norms = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
-    if rank == 0:
-        log("[bench] tables + graph: %.1fs (avg degree %.1f)" % (time.time() - t0, counts.mean()))
-
-    grouping = args.workload.startswith("grouping")
-    opq_A = None
-    vectors = tb["centroids"]
-    if flags.get("opq") and not grouping:
-        # OPQ: the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800);
-        # for a throughput corpus the synthetic centroids simply ARE the rotated ones
-        opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
-    if grouping:
-        gt = synth.make_grouping_tables(args.seed + 3, tb, 64, device=dev)
-        opq_A = synth.random_rotation(np.random.default_rng(args.seed + 4), d)
-        # the graph holds rotated centroids at search time (rotate_quantizer, IndexIVF_HNSW.cpp:789-800)
-        vectors = synth.rotated_vectors(tb["centroids"], opq_A)
-    g = pkg.GpuIndex(local_rank)
-    code_seed = args.seed + 7
-    t0 = time.time()
-    g.upload_ivf_synthetic(d, M, tb["offsets"], centroid_norms, tb["pq_centroids"], tb["norm_table"], code_seed,
-                           opq_A=opq_A, shard_rank=rank, shard_world=world)
-    g.upload_quantizer(counts, links, vectors, 0)
-    if grouping:
-        g.upload_grouping(64, gt["alphas"], gt["nn_centroid_idxs"], gt["subgroup_sizes"], gt["inter_centroid_dists"])
-    if rank == 0:
-        log("[bench] corpus on device: %.1fs, %.2f GB held" % (time.time() - t0, g.memory_bytes() / 1e9))
+    grouping = C.grouping
+    if args.batch > 0:
+        nq = args.batch
+    elif args.scaling == "strong":
+        nq = STRONG_BATCH
+    else:
+        nq = C.nq * world * args.scale
+    queries = C.queries(nq, args.seed + 1)
 
     # everything the timed region touches lives in HBM already
     g.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -177,24 +259,29 @@ def main():
     barrier()
     g.set_profiling(True)
     g.reset_stage_ms()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t_start
+    elapsed = timed_steps(torch, step, barrier, args.steps)
     if rank == 0:
         log("[bench] timed region: %d steps in %.3fs" % (args.steps, elapsed))
     stage = g.stage_ms()
     g.set_profiling(False)
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
-    # the host-pointer entry point of the C ABI (queries in, distances and labels out over PCIe): never `value`,
-    # reported beside it
+    lab_gpu = d_lab.cpu().numpy()[:, 0].copy()
+    dist_gpu = d_dist.cpu().numpy()[:, 0].copy()
+
+    # the same step sustained for >= 1 s (the K-step region above is tens of milliseconds: too short for the clocks
+    # and the driver's SMI sampler to mean anything); stage events off, results must not change
+    n_sus = max(args.steps, int(math.ceil(args.sustain_s / max(1e-6, elapsed / args.steps))))
+    t_sus = timed_steps(torch, step, barrier, n_sus) if args.sustain_s > 0 else 0.0
+    sus_same = bool((d_lab.cpu().numpy()[:, 0] == lab_gpu).all())
+
+    # the host-pointer entry point of the C ABI (queries in, distances and labels out over PCIe): SURVEY 8d's
+    # end-to-end figure; never `value` (the contract wants inputs resident in HBM), reported beside it
     host_qps = None
     if world == 1:
-        g.search(queries[:nq], 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        g.search(queries, 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         t_h = time.perf_counter()
         for _ in range(3):
-            g.search(queries[:nq], 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+            g.search(queries, 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         host_qps = 3 * nq / (time.perf_counter() - t_h)
 
     # Serving form (reported beside `value`, never as it): --in-flight batches on as many streams, each on its own
@@ -212,31 +299,31 @@ def main():
         for h, st, dd, ll in ctxs:   # warm-up: every view sizes its workspace
             h.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         torch.cuda.synchronize()
+        n_pipe = max(args.steps, n_sus // 2)
         t_p = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(n_pipe):
             h, st, dd, ll = ctxs[i % len(ctxs)]
             h.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         torch.cuda.synchronize()
         el_p = time.perf_counter() - t_p
         same = all(bool(torch.equal(ll, d_lab)) and bool(torch.equal(dd.view(torch.int32), d_dist.view(torch.int32)))
                    for _, _, dd, ll in ctxs[1:])
-        pipe = {"in_flight": len(ctxs), "queries_per_s": round(nq * args.steps / el_p, 1),
-                "ms_per_batch": round(el_p / args.steps * 1e3, 4), "results_equal_to_sequential": same}
+        pipe = {"in_flight": len(ctxs), "steps": n_pipe, "queries_per_s": round(nq * n_pipe / el_p, 1),
+                "ms_per_batch": round(el_p / n_pipe * 1e3, 4), "results_equal_to_sequential": same}
         for h, _, _, _ in ctxs[1:]:
             h.close()
         g.set_stream(torch.cuda.current_stream().cuda_stream)
 
     red_dev = dev if backend == "nccl" else torch.device("cpu")
-    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    nc_t = torch.tensor([float(ncodes)], dtype=torch.float64, device=red_dev)
+    red = torch.tensor([elapsed, t_sus], dtype=torch.float64, device=red_dev)
+    nc_sum = torch.tensor([float(ncodes)], dtype=torch.float64, device=red_dev)
+    nc_max = nc_sum.clone()
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(nc_t, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    ncodes_all = float(nc_t.item())
-
-    lab_gpu = d_lab.cpu().numpy()[:, 0]
-    dist_gpu = d_dist.cpu().numpy()[:, 0]
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nc_sum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(nc_max, op=dist.ReduceOp.MAX)
+    elapsed, t_sus = float(red[0].item()), float(red[1].item())
+    ncodes_all = float(nc_sum.item())
 
     if rank == 0 and args.dump:
         np.savez(args.dump, labels=lab_gpu, dist=dist_gpu)
@@ -244,25 +331,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         qps = nq * args.steps / elapsed
-        scan_ms, scan_n = stage["scan"]
-        scan_avg_ms = scan_ms / max(1, scan_n)
-        bytes_per_code = M + 1  # PQ code + norm code
-        achieved = bytes_per_code * ncodes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-        # HBM bytes per launch of the scan kernel, measured by the rocprofv3 PMC passes committed under profiles/
-        # (bench.py cannot collect counters itself); only reported for the workload they were taken on.
-        traffic = None
-        walk_traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json")))
-            if tj.get("workload") == args.workload and scale == 1 and world == 1:
-                traffic = round(tj["bytes_per_launch"] / 1e9, 4)
-                walk_traffic = round(tj["walk_bytes_per_launch"] / 1e9, 4)
-        except (OSError, ValueError, KeyError):
-            pass
+        single = world == 1 and args.scale == 1 and args.batch == 0 and args.scaling == "weak"
+        traffic, walk_traffic = pmc_traffic(args.workload) if single else (None, None)
         walk_ms, walk_n = stage["coarse"]
         walk_avg_ms = walk_ms / max(1, walk_n)
+        walk_gbps = None if walk_traffic is None or walk_avg_ms <= 0 else round(walk_traffic / (walk_avg_ms * 1e-3), 1)
+        if world == 1:
+            sharding = "replicas=1"
+        else:
+            sharding = ("lists by owner table (%s partition), %s" % (args.partition,
+                        "RCCL min-merge" if backend == "nccl" else "%s min-merge (single-GPU rehearsal)" % backend))
         out = {
-            "metric": "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak",
+            "metric": METRIC,
             "value": round(qps, 1),
             "unit": "queries/s",
             "n_gpus": world,
@@ -270,50 +350,45 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": args.workload + ("" if scale == 1 else " x%d" % scale), "n_vectors": n_total, "nc": nc, "d": d, "code_size": M,
-                "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef, "batch": nq, "k": 1,
-                "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq, 1),
-                "sharding": "replicas=1" if world == 1 else "lists c%%%d, RCCL min-merge" % world,
+                "workload": args.workload + ("" if args.scale == 1 else " x%d" % args.scale), "n_vectors": C.n_total,
+                "nc": C.nc, "d": d, "code_size": M, "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef,
+                "batch": nq, "k": 1, "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq, 1),
+                "sharding": sharding,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "scan_k1_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/scan_traffic.json)",
-                "algorithmic_gb_per_launch": round(bytes_per_code * ncodes / 1e9, 4),
-                "bytes_per_code": bytes_per_code, "codes_per_launch": ncodes, "avg_launch_ms": round(scan_avg_ms, 4),
-            },
-            # the kernel most of the step is spent in: its own HBM bytes (PMC) over its launch time; the reference's
-            # dist_calc count (dist_evals x 4d bytes) is added by the cpu_baseline leg, which counts it
+            "value_is": "device-resident rate (queries and results in HBM, bench contract); SURVEY 8d's end-to-end "
+                        "figure incl. H2D/D2H is host_pointer_queries_per_s",
+            "sustained": {"steps": n_sus, "seconds": round(t_sus, 3),
+                          "queries_per_s": round(nq * n_sus / t_sus, 1) if t_sus > 0 else None,
+                          "results_unchanged": sus_same},
+            "roofline": scan_roofline(g, M, stage, traffic),
+            # the kernel most of the step is spent in.  frac = its own HBM-side bytes (PMC) over its launch time, as a
+            # fraction of the HBM peak; the reference's dist_calc accounting (dist_evals x 4d bytes, rows
+            # the kernel's exact rejection filter mostly does not read) is reported separately by the cpu_baseline leg
             "roofline_walk": {
-                "bound": "hbm", "kernel": "hnsw_walk_kernel", "avg_launch_ms": round(walk_avg_ms, 4),
-                "traffic": walk_traffic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "traffic_gbps": None if walk_traffic is None or walk_avg_ms <= 0
-                else round(walk_traffic / (walk_avg_ms * 1e-3), 1),
+                "bound": "latency / vector ALU (DESIGN.md 3.2), reported against HBM", "kernel": "hnsw_walk_kernel",
+                "avg_launch_ms": round(walk_avg_ms, 4), "traffic": walk_traffic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
         }
+        if world > 1:
+            out["shard_balance"] = {"codes_per_step_max_rank": float(nc_max.item()),
+                                    "codes_per_step_mean_rank": round(ncodes_all / world, 1),
+                                    "max_over_mean": round(float(nc_max.item()) / max(1.0, ncodes_all / world), 4)}
 
-        if world == 1 and scale == 1 and not args.no_cpu_baseline:
+        ox = None
+        if world == 1 and args.scale == 1 and not args.no_cpu_baseline:
             # the oracle (a port of the reference's CPU path) on the same corpus, bounded sample of the same batch
             from oracle import orc
             t0 = time.time()
-            ids_h, codes_h, ncodes_h = synth.synthetic_codes(code_seed, tb["offsets"], M)
-            graph = orc.Hnsw.from_arrays(counts, links, vectors, 16, 0)
-            if grouping:
-                ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h,
-                               ncodes_h, centroid_norms, opq_A=opq_A, nsubc=64, alphas=gt["alphas"],
-                               nn_centroid_idxs=gt["nn_centroid_idxs"], subgroup_sizes=gt["subgroup_sizes"],
-                               inter_centroid_dists=gt["inter_centroid_dists"])
-            else:
-                ox = orc.Index(d, M, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], ids_h, codes_h,
-                               ncodes_h, centroid_norms, opq_A=opq_A)
+            ox = C.oracle(synth, orc)
             ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
             log("[bench] host corpus for the CPU baseline: %.1fs" % (time.time() - t0))
             # the GPU box gives one GPU's share of the host (16 cores); more OpenMP threads than that only spin
@@ -347,22 +422,78 @@ def main():
             walk_alg = evals_q * 4 * d * nq
             rw = out["roofline_walk"]
             rw["dist_evals_per_query"] = round(evals_q, 1)
-            rw["algorithmic_gb_per_launch"] = round(walk_alg / 1e9, 4)
-            rw["achieved"] = round(walk_alg / 1e9 / (walk_avg_ms * 1e-3), 1) if walk_avg_ms > 0 else 0.0
-            rw["frac"] = round(rw["achieved"] / HBM_PEAK_GBPS, 4)
-            rw["note"] = ("achieved counts the rows the reference's walk evaluates; the kernel's exact rejection "
-                          "filter reads most of them as 32-byte rows instead, hence traffic < algorithmic")
+            rw["reference_rows_gb_per_launch"] = round(walk_alg / 1e9, 4)
+            rw["reference_rows_gbps"] = round(walk_alg / 1e9 / (walk_avg_ms * 1e-3), 1) if walk_avg_ms > 0 else 0.0
+            rw["note"] = ("reference_rows_* counts the 4d-byte rows the reference's walk evaluates (its dist_calc); the "
+                          "kernel's exact rejection filter settles most of them from byte rows, so this is not a "
+                          "fraction of anything -- frac is traffic_gbps / peak")
             same_l = int((rl_all[:, 0] == lab_gpu).sum())
             same_d = int((rd_all[:, 0].view(np.uint32) == dist_gpu.view(np.uint32)).sum())
             out["parity"] = {"queries_checked": nq, "labels_equal": same_l, "distances_bit_equal": same_d}
             if same_l != nq or same_d != nq:
                 log("[bench] PARITY FAILURE: %d/%d labels, %d/%d distances" % (same_l, nq, same_d, nq))
+
+        # secondary results in the same line: the 1B corpus at configs[2]'s operating point, and configs[1]
+        if single and args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
+            out["secondary"] = []
+            sec = [("synthetic-1B-pq16-nc993127-nprobe64", C, ox), ("synthetic-100M-pq16-nc131072-nprobe32", None, None)]
+            for name, CC, oxx in sec:
+                own = CC is None
+                if own:
+                    CC = Corpus(pkg, synth, name, args.seed, dev, local_rank)
+                    CC.g.set_stream(torch.cuda.current_stream().cuda_stream)
+                _, _, _, _, s_np, s_mc, s_ef, s_nq = WORKLOADS[name]
+                sq = queries if not own else CC.queries(s_nq, args.seed + 1)
+                s_dq = torch.from_numpy(sq).to(dev)
+                s_dd = torch.empty((s_nq, 1), dtype=torch.float32, device=dev)
+                s_ll = torch.empty((s_nq, 1), dtype=torch.int64, device=dev)
+                gg = CC.g
+
+                def s_step():
+                    gg.search_dev(s_nq, 1, s_dq, s_dd, s_ll, s_np, s_mc, efSearch=s_ef)
+
+                for _ in range(3 + args.warmup):
+                    s_step()
+                torch.cuda.synchronize()
+                gg.set_profiling(True)
+                gg.reset_stage_ms()
+                t_s = timed_steps(torch, s_step, torch.cuda.synchronize, args.steps)
+                s_stage = gg.stage_ms()
+                gg.set_profiling(False)
+                ent = {"workload": name, "value": round(s_nq * args.steps / t_s, 1), "unit": "queries/s",
+                       "ms_per_step": round(t_s / args.steps * 1e3, 4), "nprobe": s_np, "max_codes": s_mc,
+                       "efSearch": s_ef, "batch": s_nq,
+                       "roofline": scan_roofline(gg, CC.M, s_stage, pmc_traffic(name)[0]),
+                       "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in s_stage.items()}}
+                if not args.no_cpu_baseline:
+                    from oracle import orc
+                    if oxx is None:
+                        oxx = CC.oracle(synth, orc)
+                    oxx.set_params(s_np, s_mc, s_ef)
+                    n_chk = 2000
+                    try:
+                        nthr = min(16, len(os.sched_getaffinity(0)))
+                    except AttributeError:
+                        nthr = 8
+                    r_d, r_l, _, _, _ = oxx.search_batch(sq[:n_chk], 1, nthr)
+                    lg, dg = s_ll.cpu().numpy()[:n_chk, 0], s_dd.cpu().numpy()[:n_chk, 0]
+                    ent["parity"] = {"queries_checked": n_chk, "labels_equal": int((r_l[:, 0] == lg).sum()),
+                                     "distances_bit_equal": int((r_d[:, 0].view(np.uint32) == dg.view(np.uint32)).sum())}
+                out["secondary"].append(ent)
+                if own:
+                    gg.close()
         print(json.dumps(out), flush=True)
 
     g.close()
     if world > 1:
         dist.destroy_process_group()
-    if out is not None and "parity" in out and out["parity"]["labels_equal"] != out["parity"]["queries_checked"]:
+    bad = False
+    if out is not None:
+        for ent in [out] + out.get("secondary", []):
+            p = ent.get("parity")
+            if p and (p["labels_equal"] != p["queries_checked"] or p["distances_bit_equal"] != p["queries_checked"]):
+                bad = True
+    if bad:
         sys.exit(3)
 
 
