@@ -97,7 +97,7 @@ struct ivfhnsw_gpu {
 
     // per-batch workspace
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
-        w_slen;
+        w_slen, w_counter;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
 
@@ -342,7 +342,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     if (h->own_stream)
@@ -1088,8 +1088,6 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
 
     const int d = h->t.d, M = h->t.M, nprobe = (int)p->nprobe;
     const int max_seg = h->has_group ? nprobe * h->g.nsubc : nprobe;
-    if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
-        return rc;
     if ((rc = h->w_segs.ensure(nq * (size_t)max_seg * sizeof(Seg))))
         return rc;
     if ((rc = h->w_lpos.ensure(nq * (size_t)max_seg * sizeof(uint32_t))))
@@ -1140,13 +1138,21 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
                                     h->w_keys.as<uint64_t>(), (int)k));
         }
     }
+    // a plan segment is a list (IVFADC) or a sub-group (Grouping): the mean length decides the scan form
+    const uint64_t nseg_all = (uint64_t)h->t.nc * (h->has_group ? (uint64_t)h->g.nsubc : 1);
+    const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
+    const bool heap = p->heap_order && k > 1;
+    // k = 1 on the common shapes: table and scan fused, the table never leaves the chip (kernels_scan2.hip)
+    const bool fused = k == 1 && scan_fused_supported(h->t);
+    const bool short_segments = seg_hint > 0 && seg_hint <= 48;
     // 4. table (IndexIVF_HNSW.cpp:262)
-    {
+    if (!fused) {
+        if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
+            return rc;
         StageScope sc(h, IVFHNSW_STAGE_LUT);
         HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq, h->w_hdr.as<PlanHdr>()));
     }
     // 5. scan (IndexIVF_HNSW.cpp:282-289)
-    const bool heap = p->heap_order && k > 1;
     if (heap) {
         if (d_out_keys)
             return fail(IVFHNSW_ERR_INVALID, "heap_order is not available together with out_keys (sharded merge)");
@@ -1160,15 +1166,21 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         int nsplit = 1;
         if (k == 1 && nq < 1024)
             nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
+        if (fused && (rc = h->w_counter.ensure(sizeof(uint32_t))))
+            return rc;
         StageScope sc(h, IVFHNSW_STAGE_SCAN);
-        // a plan segment is a list (IVFADC) or a sub-group (Grouping): the mean length decides the scan form
-        const uint64_t nseg_all = (uint64_t)h->t.nc * (h->has_group ? (uint64_t)h->g.nsubc : 1);
-        const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
-        HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
-                            h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
-                            heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
-                            heap ? kHeapStreamCap : 0, seg_hint));
-        h->last_scan_kernel = last_scan_kernel_name();
+        if (fused) {
+            HIP_TRY(launch_scan_fused(h->stream, h->t, xq, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                                      h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, nsplit, h->w_keys.as<uint64_t>(),
+                                      h->w_counter.as<uint32_t>(), short_segments));
+            h->last_scan_kernel = short_segments ? "scan_fused_kernel (short segments)" : "scan_fused_kernel";
+        } else {
+            HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                                h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
+                                heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
+                                heap ? kHeapStreamCap : 0, seg_hint));
+            h->last_scan_kernel = last_scan_kernel_name();
+        }
     }
     // 6. select
     {
@@ -1312,7 +1324,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

@@ -365,6 +365,30 @@ __device__ __forceinline__ float adc_sum(const float *s_lut, const uint32_t (&w)
     return sum;
 }
 
+// faiss's SSE fvec_inner_product (the order of pq->compute_inner_prod_table, IndexIVF_HNSW.cpp:262): 4 partial sums
+// over blocks of 4, zero-padded tail, then (s0+s1)+(s2+s3).
+template <int DSUB>
+__device__ __forceinline__ float ip_sse_order(const float *x, const float *y, int dsub_rt)
+{
+    const int dsub = DSUB > 0 ? DSUB : dsub_rt;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= dsub; i += 4) {
+        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
+        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
+        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
+        s3 = __fadd_rn(s3, __fmul_rn(x[i + 3], y[i + 3]));
+    }
+    if (i < dsub)
+        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
+    if (i + 1 < dsub)
+        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
+    if (i + 2 < dsub)
+        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
+    return __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
+}
+
 // One code's bytes between its load and its use.  CS > 0: the code words stay in registers (all loads of an unrolled
 // step are issued before the first table lookup).  CS == 0 is the run-time form for code sizes without an
 // instantiation of their own (any multiple of 4, IndexIVF_HNSW.cpp:805): the sum is taken word by word as the code

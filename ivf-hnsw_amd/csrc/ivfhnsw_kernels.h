@@ -100,6 +100,11 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys,
                        uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0,
                        int seg_len_hint = 0); // expected codes per plan segment (0 = unknown): picks the scan form
+// table + scan in one persistent kernel, code book in registers (kernels_scan2.hip); k = 1, PQ16 / PQ8 at d = 128, 96
+bool scan_fused_supported(const IvfTables &t);
+hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
+                             const PlanHdr *hdr, int max_seg, int nq, int nsplit, uint64_t *keys, uint32_t *counter,
+                             bool short_segments); // short_segments: sub-group plans (Grouping), see kernels_scan2.hip
 const char *last_scan_kernel_name(); // the kernel the calling thread's last launch_scan chose
 // k > 1 in faiss heap-array order: sequential replay of the top-k kernel's candidate stream
 hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,

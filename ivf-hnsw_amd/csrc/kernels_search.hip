@@ -98,28 +98,6 @@ hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, 
 constexpr int LUT_QB = 4;
 
 template <int DSUB>
-__device__ __forceinline__ float ip_sse_order(const float *x, const float *y, int dsub_rt)
-{
-    const int dsub = DSUB > 0 ? DSUB : dsub_rt;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-#pragma unroll
-    for (; i + 4 <= dsub; i += 4) {
-        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
-        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
-        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
-        s3 = __fadd_rn(s3, __fmul_rn(x[i + 3], y[i + 3]));
-    }
-    if (i < dsub)
-        s0 = __fadd_rn(s0, __fmul_rn(x[i], y[i]));
-    if (i + 1 < dsub)
-        s1 = __fadd_rn(s1, __fmul_rn(x[i + 1], y[i + 1]));
-    if (i + 2 < dsub)
-        s2 = __fadd_rn(s2, __fmul_rn(x[i + 2], y[i + 2]));
-    return __fadd_rn(__fadd_rn(s0, s1), __fadd_rn(s2, s3));
-}
-
-template <int DSUB>
 __global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, const float *__restrict__ cb,
                                                   float *__restrict__ luts, int nq, int d, int M, int dsub_rt,
                                                   const PlanHdr *__restrict__ hdr)
