@@ -1143,8 +1143,8 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
     const bool heap = p->heap_order && k > 1;
     // k = 1 on the common shapes: table and scan fused, the table never leaves the chip (kernels_scan2.hip)
-    const bool fused = k == 1 && scan_fused_supported(h->t);
     const bool short_segments = seg_hint > 0 && seg_hint <= 48;
+    const bool fused = k == 1 && scan_fused_supported(h->t, short_segments);
     // 4. table (IndexIVF_HNSW.cpp:262)
     if (!fused) {
         if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))

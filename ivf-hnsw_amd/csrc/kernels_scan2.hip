@@ -340,16 +340,25 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 } // namespace
 
-bool scan_fused_supported(const IvfTables &t)
+// Where the fused form is used (measured on MI355X, 1B codes, 10 k queries, profiles/r02_fused_ab.md):
+//   * sub-group plans (Grouping): 0.561 ms against 0.053 (tables) + 0.579 (scan_k1_short_kernel);
+//   * list shards of a multi-GPU index: every rank would otherwise build, write and stage the table of (nearly)
+//     every query of the N-times larger batch for 1/N of its codes;
+//   * one GPU, whole lists: NOT used -- 0.506 ms against 0.052 + 0.366: at 4 waves per SIMD the per-query chain
+//     (queue, plan, table, scan, reduce) of two workgroups per CU hides less than eight independent workgroups do.
+// IVFHNSW_SCAN_FUSED = 0 never, 1 always (where the shape is supported), unset = the rule above.
+bool scan_fused_supported(const IvfTables &t, bool short_segments)
 {
-    // IVFHNSW_SCAN_FUSED=0 keeps lut_kernel + scan_k1_kernel (A/B runs)
-    static const bool off = [] {
+    static const int knob = [] {
         const char *e = getenv("IVFHNSW_SCAN_FUSED");
-        return e && atoi(e) == 0;
+        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
-    if (off)
+    if (knob == 0)
         return false;
-    return (t.M == 16 && (t.dsub == 8 || t.dsub == 6)) || (t.M == 8 && (t.dsub == 16 || t.dsub == 12));
+    const bool shape = (t.M == 16 && (t.dsub == 8 || t.dsub == 6)) || (t.M == 8 && (t.dsub == 16 || t.dsub == 12));
+    if (!shape)
+        return false;
+    return knob == 1 || short_segments || t.shard_world > 1;
 }
 
 hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
