@@ -149,6 +149,21 @@ int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_q
 int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *d_keys,
                                  float *d_distances, int64_t *d_labels);
 
+/* k > 1 across shards.  Ascending order: all-gather the out_keys of every shard and keep the k smallest
+ * per query, then resolve.  The reference's heap-array order (IndexIVF_HNSW.cpp:265,285-288) needs the sequence of
+ * admitted codes in scan order: search_dev with heap_order = 1 AND out_keys leaves each shard's candidate stream -- a
+ * superset of the codes faiss's heap admits, in this shard's scan order, as (orderable distance << 32 | scan position)
+ * keys -- copied out by last_stream_dev: d_len ([nq], nullable) receives the stream lengths, d_keys ([nq][len_cap],
+ * nullable) the first len_cap keys of every query's stream, *stream_cap (nullable) the library's capacity; a length
+ * above that capacity means the stream overflowed: use ascending order.  The caller merges the shards' streams by
+ * scan position and hands the merged stream to replay_stream_dev, which replays faiss's pop/push over it and writes
+ * the heap ARRAY as signed keys ([nq*k], unfilled slots = the FLT_MAX key); resolve_keys_dev + MAX-reduce then give
+ * labels.  Replaying a superset in scan order is exact: a code failing `dist < distances[0]` leaves the heap as it is. */
+int ivfhnsw_gpu_last_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint64_t *d_keys, uint32_t *d_len,
+                                uint32_t *stream_cap);
+int ivfhnsw_gpu_replay_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const uint64_t *d_stream, const uint32_t *d_len,
+                                  uint32_t cap, int64_t *d_out_keys);
+
 /* The coarse stage alone (HierarchicalNSW::searchKnn, hnswalg.cpp:227-234, plus the unload loop of
  * IndexIVF_HNSW.cpp:249-259): device pointers, [nq*nprobe] outputs, nearest first.  Queries must
  * already be rotated when OPQ is on. */

@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
+    "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev",
 )
 
 
@@ -97,6 +98,10 @@ def lib():
         L.ivfhnsw_gpu_reset_stage_ms.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_memory_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ivfhnsw_gpu_last_stream_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(C.c_uint32)]
+        L.ivfhnsw_gpu_replay_stream_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                    C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
@@ -229,9 +234,9 @@ class GpuIndex:
         return dist, lab
 
     def search_dev(self, nq, k, d_queries, d_distances, d_labels, nprobe, max_codes, d_coarse_ids=None,
-                   d_coarse_dists=None, efSearch=0, do_pruning=False, d_out_keys=None):
+                   d_coarse_dists=None, efSearch=0, do_pruning=False, d_out_keys=None, heap_order=False):
         """Device buffers (torch CUDA tensors), asynchronous on the handle's stream."""
-        p = self._params(nprobe, max_codes, efSearch, do_pruning)
+        p = self._params(nprobe, max_codes, efSearch, do_pruning, heap_order)
         _check(lib().ivfhnsw_gpu_search_dev(self._h, nq, k, _devptr(d_queries), _devptr(d_coarse_ids),
                                             _devptr(d_coarse_dists), C.byref(p), _devptr(d_distances),
                                             _devptr(d_labels), _devptr(d_out_keys)))
@@ -239,6 +244,17 @@ class GpuIndex:
     def resolve_keys_dev(self, nq, k, d_keys, d_distances, d_labels):
         _check(lib().ivfhnsw_gpu_resolve_keys_dev(self._h, nq, k, _devptr(d_keys), _devptr(d_distances),
                                                   _devptr(d_labels)))
+
+    def last_stream_dev(self, nq, len_cap=0, d_keys=None, d_len=None):
+        """Copy out the candidate streams the last search_dev (k > 1, heap_order, out_keys) left: lengths into d_len
+        ([nq] int32), the first len_cap keys of each into d_keys ([nq, len_cap] int64).  Returns the stream capacity."""
+        cap = C.c_uint32()
+        _check(lib().ivfhnsw_gpu_last_stream_dev(self._h, nq, len_cap, _devptr(d_keys), _devptr(d_len), C.byref(cap)))
+        return cap.value
+
+    def replay_stream_dev(self, nq, k, d_stream, d_len, cap, d_out_keys):
+        _check(lib().ivfhnsw_gpu_replay_stream_dev(self._h, nq, k, _devptr(d_stream), _devptr(d_len), cap,
+                                                   _devptr(d_out_keys)))
 
     def rotate_dev(self, nq, d_queries, d_out):
         """opq_matrix->apply on device buffers (a copy when the index has no OPQ matrix)."""

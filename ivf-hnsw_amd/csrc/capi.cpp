@@ -103,6 +103,7 @@ struct ivfhnsw_gpu {
 
     int last_nq = 0, last_max_seg = 0;
     const char *last_scan_kernel = "";
+    bool last_stream = false; // the last search left a candidate stream (k > 1, heap_order)
 
     bool profiling = false;
     std::vector<StageEvent> pending;
@@ -1154,8 +1155,8 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     }
     // 5. scan (IndexIVF_HNSW.cpp:282-289)
     if (heap) {
-        if (d_out_keys)
-            return fail(IVFHNSW_ERR_INVALID, "heap_order is not available together with out_keys (sharded merge)");
+        // with out_keys (sharded search) the replay is the caller's: it merges the shards' candidate streams in scan
+        // order first (ivfhnsw_gpu_last_stream_dev, ivfhnsw_gpu_replay_stream_dev)
         if ((rc = h->w_stream.ensure(nq * (size_t)kHeapStreamCap * sizeof(uint64_t))))
             return rc;
         if ((rc = h->w_slen.ensure(nq * sizeof(uint32_t))))
@@ -1185,16 +1186,17 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     // 6. select
     {
         StageScope sc(h, IVFHNSW_STAGE_SELECT);
-        if (heap)
+        if (heap && !d_out_keys)
             HIP_TRY(launch_heap_replay(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
                                        h->w_stream.as<uint64_t>(), h->w_slen.as<uint32_t>(), kHeapStreamCap, (int)nq,
-                                       (int)k, d_distances, d_labels, h->w_status.as<uint32_t>()));
+                                       (int)k, d_distances, d_labels, h->w_status.as<uint32_t>(), nullptr));
         else
             HIP_TRY(launch_select(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
                                   h->w_keys.as<uint64_t>(), (int)nq, (int)k, d_distances, d_labels, d_out_keys));
     }
     h->last_nq = (int)nq;
     h->last_max_seg = max_seg;
+    h->last_stream = heap;
     return IVFHNSW_OK;
 }
 
@@ -1209,6 +1211,45 @@ int ivfhnsw_gpu_resolve_keys_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const int6
     StageScope sc(h, IVFHNSW_STAGE_SELECT);
     HIP_TRY(launch_resolve(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), h->last_max_seg, d_keys,
                            (int)nq, (int)k, d_distances, d_labels));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_last_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint64_t *d_keys, uint32_t *d_len,
+                                uint32_t *stream_cap)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->last_nq || !h->last_stream || (size_t)h->last_nq != nq)
+        return fail(IVFHNSW_ERR_STATE, "last_stream needs a preceding search_dev of the same nq with k > 1 and heap_order = 1");
+    if (stream_cap)
+        *stream_cap = kHeapStreamCap;
+    if (d_len)
+        HIP_TRY(hipMemcpyAsync(d_len, h->w_slen.p, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+    if (d_keys) {
+        if (len_cap == 0 || len_cap > kHeapStreamCap)
+            return fail(IVFHNSW_ERR_INVALID, "len_cap %zu outside 1..%u", len_cap, kHeapStreamCap);
+        HIP_TRY(hipMemcpy2DAsync(d_keys, len_cap * sizeof(uint64_t), h->w_stream.p, (size_t)kHeapStreamCap * sizeof(uint64_t),
+                                 len_cap * sizeof(uint64_t), nq, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_replay_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const uint64_t *d_stream, const uint32_t *d_len,
+                                  uint32_t cap, int64_t *d_out_keys)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "replay_stream before upload_ivf");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!d_stream || !d_len || !d_out_keys || k == 0 || k > 1024 || nq > 0x7fffffffull / k)
+        return fail(IVFHNSW_ERR_INVALID, "bad replay_stream arguments (k %zu)", k);
+    StageScope sc(h, IVFHNSW_STAGE_SELECT);
+    HIP_TRY(launch_heap_replay(h->stream, h->t, nullptr, nullptr, 0, d_stream, d_len, cap, (int)nq, (int)k, nullptr,
+                               nullptr, h->w_status.as<uint32_t>(), d_out_keys));
     return IVFHNSW_OK;
 }
 

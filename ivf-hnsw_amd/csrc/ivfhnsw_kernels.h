@@ -109,7 +109,8 @@ const char *last_scan_kernel_name(); // the kernel the calling thread's last lau
 // k > 1 in faiss heap-array order: sequential replay of the top-k kernel's candidate stream
 hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
                               const uint64_t *stream, const uint32_t *stream_len, uint32_t stream_cap, int nq, int k,
-                              float *dist, int64_t *labels, uint32_t *status);
+                              float *dist, int64_t *labels, uint32_t *status,
+                              int64_t *out_keys = nullptr); // non-null: the heap array as signed keys, no labels (sharded)
 // keys -> (distance, label) through the plan; also emits signed-orderable keys when out_keys != null
 hipError_t launch_select(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
                          const uint64_t *keys, int nq, int k, float *dist, int64_t *labels, int64_t *out_keys);

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void heap_replay_kernel(IvfTables t, const Seg
                                                           const unsigned long long *__restrict__ stream,
                                                           const uint32_t *__restrict__ stream_len, uint32_t stream_cap,
                                                           int nq, int k, float *__restrict__ dist,
-                                                          long long *__restrict__ labels, uint32_t *__restrict__ status)
+                                                          long long *__restrict__ labels, uint32_t *__restrict__ status,
+                                                          long long *__restrict__ out_keys)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -308,12 +309,17 @@ __global__ __launch_bounds__(256) void heap_replay_kernel(IvfTables t, const Seg
     const uint32_t len = stream_len[q];
     float *out_d = dist + (size_t)q * k;
     long long *out_l = labels + (size_t)q * k;
+    long long *out_k = out_keys ? out_keys + (size_t)q * k : nullptr;
     if (len > stream_cap) {
         if (lane == 0)
             atomicOr(status, kStatusTopkStreamOverflow);
         for (int j = lane; j < k; j += 64) {
-            out_d[j] = FLT_MAX;
-            out_l[j] = -1;
+            if (out_k) {
+                out_k[j] = (long long)(kKeyInit ^ kSignFlip);
+            } else {
+                out_d[j] = FLT_MAX;
+                out_l[j] = -1;
+            }
         }
         return;
     }
@@ -340,8 +346,18 @@ __global__ __launch_bounds__(256) void heap_replay_kernel(IvfTables t, const Seg
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // labels of the survivors (segments ascend in vpos)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (out_k) {
+        // sharded search: the heap array as packed (distance, scan position) keys; the owner of each position resolves
+        // its label afterwards (ivfhnsw_gpu_resolve_keys_dev)
+        for (int j = lane; j < k; j += 64) {
+            const unsigned long long key =
+                pos[j] == 0xffffffffu ? kKeyInit : (((unsigned long long)f32_orderable(val[j]) << 32) | pos[j]);
+            out_k[j] = (long long)(key ^ kSignFlip);
+        }
+        return;
+    }
+    // labels of the survivors (segments ascend in vpos)
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t nseg = hdr[q].nseg;
     for (int j = lane; j < k; j += 64) {
@@ -366,13 +382,13 @@ __global__ __launch_bounds__(256) void heap_replay_kernel(IvfTables t, const Seg
 
 hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,
                               const uint64_t *stream, const uint32_t *stream_len, uint32_t stream_cap, int nq, int k,
-                              float *dist, int64_t *labels, uint32_t *status)
+                              float *dist, int64_t *labels, uint32_t *status, int64_t *out_keys)
 {
     if (nq == 0)
         return hipSuccess;
     hipLaunchKernelGGL(heap_replay_kernel, dim3((nq + 3) / 4), dim3(256), (size_t)4 * 2 * k * sizeof(float), s, t, segs, hdr, max_seg,
                        reinterpret_cast<const unsigned long long *>(stream), stream_len, stream_cap, nq, k, dist,
-                       reinterpret_cast<long long *>(labels), status);
+                       reinterpret_cast<long long *>(labels), status, reinterpret_cast<long long *>(out_keys));
     return hipGetLastError();
 }
 

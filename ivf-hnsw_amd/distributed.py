@@ -117,24 +117,65 @@ def _all_reduce(t, op, group):
         t.copy_(host)
 
 
+def _all_gather_stack(t, group):
+    """[world, *t.shape]: every rank's tensor (RCCL: ncclAllGather; gloo: staged through the host)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+        return out
+    host = t.cpu().contiguous()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    return torch.stack(parts).to(t.device)
+
+
+def merge_topk_keys(stacked_keys, k):
+    """[world, nq, k] signed keys of the shards -> [nq, k], the k smallest per query in ascending order: the
+    reference's result SET (smallest distance, earliest scan position on ties); its order is merge_heap_order's."""
+    import torch
+    world, nq, kk = stacked_keys.shape
+    allk = stacked_keys.permute(1, 0, 2).reshape(nq, world * kk)
+    return torch.sort(allk, dim=1).values[:, :k].contiguous()
+
+
+def merge_streams(streams, lens, cap):
+    """Candidate streams of the shards ([world, nq, L] unsigned keys held in int64, [world, nq] lengths) -> one
+    stream per query in GLOBAL scan order ([nq, world * L], [nq] lengths).  Scan positions are unique across shards
+    (a position belongs to exactly one list, a list to one shard), so sorting by position interleaves the shards
+    exactly as the unsharded scan meets the codes."""
+    import torch
+    world, nq, L = streams.shape
+    idx = torch.arange(L, device=streams.device).view(1, 1, L)
+    valid = idx < lens.view(world, nq, 1).to(torch.int64)
+    pos = streams & 0xffffffff                                   # low word = scan position
+    pos = torch.where(valid, pos, torch.full_like(pos, 1 << 40))  # padding after everything real
+    pos = pos.permute(1, 0, 2).reshape(nq, world * L)
+    keys = streams.permute(1, 0, 2).reshape(nq, world * L)
+    order = torch.argsort(pos, dim=1)
+    merged = torch.gather(keys, 1, order).contiguous()
+    total = lens.to(torch.int64).sum(0).to(torch.int32).contiguous()
+    return merged, total
+
+
 class ShardedSearcher:
     """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller."""
 
-    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None):
+    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1):
         import torch
         self.g, self.rank, self.world, self.nq, self.nprobe, self.group = gpu_index, rank, world, nq, nprobe, group
+        self.k = k
         self.lo, self.hi, self.per = query_slice(nq, rank, world)
         self.cid = torch.empty((self.per * world, nprobe), dtype=torch.int32, device=device)
         self.cd = torch.empty((self.per * world, nprobe), dtype=torch.float32, device=device)
-        self.keys = torch.empty((nq, 1), dtype=torch.int64, device=device)
+        self.keys = torch.empty((nq, k), dtype=torch.int64, device=device)
         self.xrot = None  # own slice of the batch, OPQ-rotated for the coarse walk (allocated on first use)
 
-    def step(self, d_q, d_dist, d_lab, max_codes, efSearch, do_pruning=False):
-        """One batch: coarse slice -> all-gather -> scan own shard -> MIN keys -> resolve -> MAX labels.
-        With OPQ the walk runs on the rotated slice (IndexIVF_HNSW.cpp:240,248); search_dev rotates the whole batch
-        again for its tables, from the unrotated d_q."""
+    def coarse(self, d_q, efSearch):
+        """This rank's slice of the coarse stage, then the all-gather: self.cid / self.cd hold the whole batch."""
         import torch
-        import torch.distributed as dist
         g, r, per = self.g, self.rank, self.per
         if self.hi > self.lo:
             if self.xrot is None:
@@ -145,9 +186,49 @@ class ShardedSearcher:
         if self.world > 1:
             _all_gather_rows(self.cid, r, per, self.group)
             _all_gather_rows(self.cd, r, per, self.group)
-        g.search_dev(self.nq, 1, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
-                     d_coarse_dists=self.cd, do_pruning=do_pruning, d_out_keys=self.keys)
-        if self.world > 1:
+
+    def step(self, d_q, d_dist, d_lab, max_codes, efSearch, do_pruning=False, heap_order=False):
+        """One batch: coarse slice -> all-gather -> scan own shard -> merge keys -> resolve -> MAX labels.
+        With OPQ the walk runs on the rotated slice (IndexIVF_HNSW.cpp:240,248); search_dev rotates the whole batch
+        again for its tables, from the unrotated d_q.
+
+        k = 1: ONE int64 MIN all-reduce of the packed keys.  k > 1: all-gather of the shards' nq*k keys and a local
+        k-way merge (ascending), or -- heap_order, the array the reference's faiss heap leaves,
+        IndexIVF_HNSW.cpp:285-288 -- all-gather of the shards' candidate streams, merged in scan order and replayed."""
+        import torch
+        import torch.distributed as dist
+        g, k, nq = self.g, self.k, self.nq
+        self.coarse(d_q, efSearch)
+        heap = heap_order and k > 1
+        g.search_dev(nq, k, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
+                     d_coarse_dists=self.cd, do_pruning=do_pruning, d_out_keys=self.keys, heap_order=heap)
+        if self.world == 1 and not heap:
+            return
+        if k == 1:
             _all_reduce(self.keys, dist.ReduceOp.MIN, self.group)
-            g.resolve_keys_dev(self.nq, 1, self.keys, d_dist, d_lab)
+        elif not heap:
+            self.keys.copy_(merge_topk_keys(_all_gather_stack(self.keys, self.group), k))
+        else:
+            lens = torch.empty((nq,), dtype=torch.int32, device=d_q.device)
+            cap = g.last_stream_dev(nq, d_len=lens)
+            g.sync()  # torch reads below: order them after the handle's stream
+            lmax = lens.max().to(torch.int64).view(1)
+            if int(lmax.item()) > cap:
+                raise RuntimeError("candidate stream of a query exceeded %d entries: use ascending order" % cap)
+            if self.world > 1:
+                _all_reduce(lmax, dist.ReduceOp.MAX, self.group)
+            L = max(1, int(lmax.item()))
+            mine = torch.empty((nq, L), dtype=torch.int64, device=d_q.device)
+            g.last_stream_dev(nq, L, d_keys=mine)
+            g.sync()
+            if self.world > 1:
+                streams = _all_gather_stack(mine, self.group)
+                all_lens = _all_gather_stack(lens, self.group)
+            else:
+                streams, all_lens = mine.unsqueeze(0), lens.unsqueeze(0)
+            merged, total = merge_streams(streams, all_lens, cap)
+            torch.cuda.current_stream().synchronize()
+            g.replay_stream_dev(nq, k, merged, total, merged.shape[1], self.keys)
+        g.resolve_keys_dev(nq, k, self.keys, d_dist, d_lab)
+        if self.world > 1:
             _all_reduce(d_lab, dist.ReduceOp.MAX, self.group)

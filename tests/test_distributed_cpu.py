@@ -103,6 +103,122 @@ def _worker(rank, world, port, ties, out_dir):
     dist.destroy_process_group()
 
 
+def _shard_stream(c, q, cid, cd, max_codes, rank, owner, pack_keys):
+    """Every code of the lists `rank` owns, in scan order, as unsigned (orderable distance << 32 | scan position) keys
+    per query -- the trivially complete candidate stream -- plus a position -> label map."""
+    from oracle import orc
+    F = np.float32
+    off = c["offsets"].astype(np.int64)
+    M = c["code_size"]
+    streams, labels = [], []
+    for i in range(len(q)):
+        tab = orc.inner_prod_table(q[i], c["pq_centroids"], M)
+        ncode, ks, lab = 0, [], {}
+        for p, cc in enumerate(cid[i]):
+            cc = int(cc)
+            n = off[cc + 1] - off[cc]
+            if n == 0:
+                continue
+            if owner[cc] == rank:
+                codes = c["codes"][off[cc]:off[cc + 1]]
+                s = np.zeros(n, F)
+                for m in range(M):
+                    s = (s + tab[m, codes[:, m]]).astype(F)
+                term1 = F(cd[i, p] - c["centroid_norms"][cc])
+                dist = ((term1 + c["norm_table"][c["norm_codes"][off[cc]:off[cc + 1]]]).astype(F) - F(2) * s).astype(F)
+                vpos = (ncode + np.arange(n)).astype(np.uint32)
+                ks.append(pack_keys(dist, vpos).view(np.uint64) ^ np.uint64(0x8000000000000000))
+                for j in range(n):
+                    lab[int(vpos[j])] = int(c["ids"][off[cc] + j])
+            ncode += n
+            if ncode >= max_codes:
+                break
+        streams.append(np.concatenate(ks) if ks else np.zeros(0, np.uint64))
+        labels.append(lab)
+    return streams, labels
+
+
+def _worker_topk(rank, world, port, out_dir):
+    """k = 10 over gloo ranks with a spatial owner table: all-gather of the shards' k best keys -> k-way merge
+    (ascending); all-gather of the candidate streams -> merged in scan order -> faiss heap replay (heap-array order,
+    IndexIVF_HNSW.cpp:285-288).  Both against the unsharded oracle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import importlib
+    import synth
+    from oracle import orc
+    ge.load_pkg()
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = synth.make_corpus(seed=52, nc=96, d=64, M=8, n_base=6000, nq=20, efConstruction=60)
+    nprobe, max_codes, ef, k = 12, 700, 32, 10
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef)
+    ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=k)
+    nq = len(ref_l)
+    owner = D.partition_lists(c["centroids"], np.diff(c["offsets"].astype(np.int64)), world, "spatial")
+    assert set(owner.tolist()) == set(range(world))
+    streams, labels = _shard_stream(c, c["queries"], cid, cd, max_codes, rank, owner, D.pack_keys)
+    SIGN = np.uint64(0x8000000000000000)
+    init = np.uint64((0x7f7fffff | 0x80000000) << 32)
+    # local top-k, ascending, as signed keys (what search_dev leaves in out_keys)
+    loc = np.full((nq, k), init, np.uint64)
+    for i, st in enumerate(streams):
+        srt = np.sort(st)[:k]
+        loc[i, :len(srt)] = srt
+    tk = torch.from_numpy((loc ^ SIGN).view(np.int64).copy())
+    merged = D.merge_topk_keys(D._all_gather_stack(tk, None), k).numpy().view(np.uint64) ^ SIGN
+    # streams, padded to the longest of any rank
+    lens = torch.tensor([len(st) for st in streams], dtype=torch.int32)
+    lmax = lens.max().to(torch.int64).view(1)
+    dist.all_reduce(lmax, op=dist.ReduceOp.MAX)
+    L = max(1, int(lmax.item()))
+    pad = np.zeros((nq, L), np.uint64)
+    for i, st in enumerate(streams):
+        pad[i, :len(st)] = st
+    ms, total = D.merge_streams(D._all_gather_stack(torch.from_numpy(pad.view(np.int64).copy()), None),
+                                D._all_gather_stack(lens, None), 1 << 20)
+    ms = ms.numpy().view(np.uint64)
+    all_labels = [None] * world
+    dist.all_gather_object(all_labels, labels)
+    ok = True
+    for i in range(nq):
+        lab = {}
+        for r in range(world):
+            lab.update(all_labels[r][i])
+        # ascending merge == the reference's set
+        got = sorted(lab[int(v & np.uint64(0xffffffff))] for v in merged[i] if v < init)
+        ok &= got == sorted(int(x) for x in ref_l[i] if x >= 0)
+        # heap replay over the merged stream == the reference's heap array
+        hv = np.empty(k, np.float32)
+        hl = np.empty(k, np.int64)
+        orc.lib().orc_maxheap_heapify(k, orc._p(hv), orc._p(hl))
+        seq = ms[i, :int(total[i])]
+        assert (np.diff((seq & np.uint64(0xffffffff)).astype(np.int64)) > 0).all()   # global scan order
+        dd, vv = D.unpack_keys((seq ^ SIGN).view(np.int64))
+        for dj, vj in zip(dd, vv):
+            if dj < hv[0]:
+                orc.lib().orc_maxheap_pop(k, orc._p(hv), orc._p(hl))
+                orc.lib().orc_maxheap_push(k, orc._p(hv), orc._p(hl), float(dj), lab[int(vj)])
+        ok &= np.array_equal(hl, ref_l[i]) and np.array_equal(hv.view(np.uint32), ref_d[i].view(np.uint32))
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "fail")), "w").write("%s\n" % ok)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_topk_merge_equals_unsharded_oracle(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000) + world * 11
+    mp.spawn(_worker_topk, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("rank%d.ok" % r)), "rank %d: merged top-k differs from the oracle" % r
+
+
 @pytest.mark.parametrize("world,ties", [(2, False), (2, True), (3, False)])
 def test_shard_merge_equals_unsharded_oracle(tmp_path, world, ties):
     import torch.multiprocessing as mp

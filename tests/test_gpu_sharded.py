@@ -11,16 +11,25 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-def _shard_arrays(c, rank, world):
+def _owner_table(pkg, c, world, partition):
+    """list -> rank: the C ABI's default (c % world) or the balanced spatial partition of distributed.py."""
+    import importlib
+    if partition == "mod":
+        return None
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    return D.partition_lists(c["centroids"], np.diff(c["offsets"].astype(np.int64)), world, "spatial")
+
+
+def _shard_arrays(c, rank, world, owner=None):
     off = c["offsets"].astype(np.int64)
-    owned = [cc for cc in range(len(off) - 1) if cc % world == rank]
+    owned = [cc for cc in range(len(off) - 1) if (cc % world if owner is None else owner[cc]) == rank]
     sel = np.concatenate([np.arange(off[cc], off[cc + 1]) for cc in owned]) if owned else np.zeros(0, np.int64)
     return c["ids"][sel], c["codes"][sel], c["norm_codes"][sel]
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world,partition", [(2, "mod"), (3, "spatial"), (8, "spatial"), (8, "mod")])
 @pytest.mark.parametrize("grouping", [False, True])
-def test_sharded_equals_unsharded(gpu, world, grouping):
+def test_sharded_equals_unsharded(gpu, pkg, world, partition, grouping):
     import torch
     if grouping:
         c = corpus(seed=41, nc=256, d=128, M=16, n_base=30000, nq=96, nsubc=16)
@@ -37,11 +46,12 @@ def test_sharded_equals_unsharded(gpu, world, grouping):
     d_cd = torch.from_numpy(cd).to(dev)
     gr = c["graph"]
     shards, keys, total_codes = [], [], 0
+    owner = _owner_table(pkg, c, world, partition)
     for r in range(world):
         g = gpu()
-        ids, codes, ncodes = _shard_arrays(c, r, world)
+        ids, codes, ncodes = _shard_arrays(c, r, world, owner)
         g.upload_ivf(c["d"], c["code_size"], c["offsets"], ids, codes, ncodes, c["centroid_norms"], c["pq_centroids"],
-                     c["norm_table"], shard_rank=r, shard_world=world)
+                     c["norm_table"], shard_rank=r, shard_world=world, list_owner=owner)
         if grouping:
             g.upload_grouping(c["nsubc"], c["alphas"], c["nn_centroid_idxs"], c["subgroup_sizes"],
                               c["inter_centroid_dists"])
@@ -67,6 +77,82 @@ def test_sharded_equals_unsharded(gpu, world, grouping):
         dist = dd
     assert np.array_equal(label.cpu().numpy(), ref_l)
     assert np.array_equal(dist.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("grouping", [False, True])
+def test_sharded_topk_merge(gpu, pkg, world, grouping):
+    """k = 10 across shards: the k smallest of the all-gathered shard keys (ascending), and the reference's
+    heap ARRAY (IndexIVF_HNSW.cpp:285-288) from the shards' candidate streams merged in scan order and replayed --
+    the same functions ShardedSearcher.step runs behind its collectives, here on shard handles of one GPU."""
+    import importlib
+    import torch
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    if grouping:
+        c = corpus(seed=41, nc=256, d=128, M=16, n_base=30000, nq=96, nsubc=16)
+    else:
+        c = corpus(seed=11, nc=256, d=128, M=16, n_base=30000, nq=128)
+    nprobe, max_codes, ef, k = 16, 2500, 40, 10
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+    ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=k)     # faiss heap-array order
+    nq = len(ref_l)
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(c["queries"]).to(dev)
+    d_cid = torch.from_numpy(cid.astype(np.int32)).to(dev)
+    d_cd = torch.from_numpy(cd).to(dev)
+    owner = _owner_table(pkg, c, world, "spatial")
+    gr = c["graph"]
+    shards, keys, streams, lens = [], [], [], []
+    for r in range(world):
+        g = gpu()
+        ids, codes, ncodes = _shard_arrays(c, r, world, owner)
+        g.upload_ivf(c["d"], c["code_size"], c["offsets"], ids, codes, ncodes, c["centroid_norms"], c["pq_centroids"],
+                     c["norm_table"], shard_rank=r, shard_world=world, list_owner=owner)
+        if grouping:
+            g.upload_grouping(c["nsubc"], c["alphas"], c["nn_centroid_idxs"], c["subgroup_sizes"],
+                              c["inter_centroid_dists"])
+            g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+        dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        ll = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        kk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        g.search_dev(nq, k, d_q, dd, ll, nprobe, max_codes, d_coarse_ids=d_cid, d_coarse_dists=d_cd,
+                     do_pruning=grouping, d_out_keys=kk, heap_order=True)
+        ln = torch.empty((nq,), dtype=torch.int32, device=dev)
+        cap = g.last_stream_dev(nq, d_len=ln)
+        g.sync()
+        assert int(ln.max().item()) <= cap
+        shards.append((g, dd, ll))
+        keys.append(kk)
+        lens.append(ln)
+    L = max(1, max(int(ln.max().item()) for ln in lens))
+    for (g, _, _), ln in zip(shards, lens):
+        st = torch.empty((nq, L), dtype=torch.int64, device=dev)
+        g.last_stream_dev(nq, L, d_keys=st)
+        g.sync()
+        streams.append(st)
+
+    def resolve(merged):
+        label = torch.full((nq, k), -1, dtype=torch.int64, device=dev)
+        for g, dd, ll in shards:
+            g.resolve_keys_dev(nq, k, merged, dd, ll)
+            g.sync()
+            label = torch.maximum(label, ll)
+        return dd.cpu().numpy(), label.cpu().numpy()
+
+    # ascending: the reference's result set
+    asc_d, asc_l = resolve(D.merge_topk_keys(torch.stack(keys), k))
+    assert (np.diff(asc_d, axis=1) >= 0).all()
+    assert np.array_equal(np.sort(asc_l, axis=1), np.sort(ref_l, axis=1))
+    # heap-array order: element for element what faiss's heap leaves
+    merged, total = D.merge_streams(torch.stack(streams), torch.stack(lens), cap)
+    hk = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    shards[0][0].replay_stream_dev(nq, k, merged, total, merged.shape[1], hk)
+    shards[0][0].sync()
+    heap_d, heap_l = resolve(hk)
+    assert np.array_equal(heap_l, ref_l)
+    assert np.array_equal(heap_d.view(np.uint32), ref_d.view(np.uint32))
 
 
 def test_sharded_device_generated_corpus(gpu):

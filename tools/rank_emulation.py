@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""What ONE rank of an N-GPU weak-scaling step computes, run alone on one GPU (no collectives): shard 0 of N of an
-N x 100M corpus under N x 2^17 centroids; the walk for its 10 k queries, then tables + plan + scan of ITS lists for
-all N x 10 k queries.  Prints per-stage times, i.e. the compute part of bench.py --gpus N per rank.
-usage: python tools/rank_emulation.py [--world 8]"""
+"""What ONE rank of an N-GPU step computes, run alone on one GPU (no collectives): rank r's shard of the workload's
+corpus under the owner table bench.py --gpus N would use; the walk for its slice of the batch, then plan + tables +
+scan of ITS lists for all queries, then the label resolution.  Prints per-stage times -- the compute part of
+`bench.py --gpus N` per rank -- and, from the plan recomputed on the host, the codes every rank would score per step
+(max / mean: the load balance of the owner table).
+usage: python tools/rank_emulation.py [--world 8] [--rank 0] [--scaling weak|strong] [--partition spatial|mod] [--workload W]"""
 import argparse
+import importlib
 import os
 import sys
 import time
@@ -18,37 +21,44 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--partition", choices=("spatial", "mod"), default="spatial")
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
+    import bench
     import synth
     pkg = ge.load_pkg()
+    D = importlib.import_module("ivfhnsw_amd.distributed")
     dev = torch.device("cuda", 0)
-    W = args.world
-    n_total, nc, d, M, nprobe, max_codes, ef, nq1 = 100_000_000 * W, (1 << 17) * W, 128, 16, 32, 10000, 80, 10000
-    nq = nq1 * W
-    tb = synth.make_throughput_tables(1234, nc, d, M, n_total)
-    rng = np.random.default_rng(1235)
-    queries = (tb["centroids"][rng.choice(nc, nq)] + rng.normal(0, 12.0, size=(nq, d))).astype(np.float32)
-    counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
-    cn = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
-    g = pkg.GpuIndex(0)
-    g.upload_ivf_synthetic(d, M, tb["offsets"], cn, tb["pq_centroids"], tb["norm_table"], 1241, shard_rank=0, shard_world=W)
-    g.upload_quantizer(counts, links, tb["centroids"], 0)
+    W, r = args.world, args.rank
+    name = args.workload or bench.DEFAULT_WORKLOAD
+    C = bench.Corpus(pkg, synth, name, 1234, dev, 0, rank=r, world=W, partition=args.partition, pkg_dist=D)
+    g, nprobe, max_codes, ef, grouping = C.g, C.nprobe, C.max_codes, C.ef, C.grouping
+    nq = bench.STRONG_BATCH if args.scaling == "strong" else C.nq * W
+    lo, hi, per = D.query_slice(nq, r, W)
+    queries = C.queries(nq, 1235)
     g.set_stream(torch.cuda.current_stream().cuda_stream)
     d_q = torch.from_numpy(queries).to(dev)
+    xr = torch.empty_like(d_q)
+    g.rotate_dev(nq, d_q, xr)
     cid = torch.empty((nq, nprobe), dtype=torch.int32, device=dev)
     cd = torch.empty((nq, nprobe), dtype=torch.float32, device=dev)
-    g.coarse_dev(nq, d_q, nprobe, ef, cid, cd)          # what the all-gather would deliver
+    g.coarse_dev(nq, xr, nprobe, ef, cid, cd)          # what the all-gather would deliver
     dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
     ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
     kk = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-    own_c = torch.empty((nq1, nprobe), dtype=torch.int32, device=dev)
-    own_d = torch.empty((nq1, nprobe), dtype=torch.float32, device=dev)
+    own_c = torch.empty((per, nprobe), dtype=torch.int32, device=dev)
+    own_d = torch.empty((per, nprobe), dtype=torch.float32, device=dev)
 
     def step():
-        g.coarse_dev(nq1, d_q[:nq1], nprobe, ef, own_c, own_d)
-        g.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, d_coarse_ids=cid, d_coarse_dists=cd, d_out_keys=kk)
+        g.rotate_dev(hi - lo, d_q[lo:hi], xr[lo:hi])
+        g.coarse_dev(hi - lo, xr[lo:hi], nprobe, ef, own_c, own_d)
+        g.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, d_coarse_ids=cid, d_coarse_dists=cd, d_out_keys=kk,
+                     do_pruning=grouping)
         g.resolve_keys_dev(nq, 1, kk, dd, ll)
 
     for _ in range(2):
@@ -57,14 +67,30 @@ def main():
     g.set_profiling(True)
     g.reset_stage_ms()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    t = (time.perf_counter() - t0) / 5
-    st = {a: round(b[0] / 5, 3) for a, b in g.stage_ms().items()}
-    print("world %d: one rank's compute per step %.3f ms -> %.2f M queries/s aggregate if collectives were free "
-          "(N=1 measures 1.53 ms for 10 k); stages %s; codes scored here per step %d"
-          % (W, t * 1e3, nq / t / 1e6, st, g.last_scan_counts()[0]), flush=True)
+    t = (time.perf_counter() - t0) / args.steps
+    st = {a: round(b[0] / args.steps, 3) for a, b in g.stage_ms().items()}
+    here = g.last_scan_counts()[0]
+    # every rank's scored codes from the plan rule on the host (IVFADC rule; Grouping prunes inside lists, same shares)
+    bal = ""
+    if not grouping:
+        sizes = np.diff(C.tb["offsets"].astype(np.int64))
+        ids = cid.cpu().numpy().astype(np.int64)
+        sz = sizes[ids]
+        before = np.cumsum(sz, axis=1) - sz
+        take = (sz > 0) & ((before < max_codes) | (before == 0))
+        owner = C.owner if C.owner is not None else np.zeros(C.nc, np.uint32)
+        per_rank = np.bincount(owner[ids[take]], weights=sz[take], minlength=W)
+        ranks_per_q = np.array([len(set(owner[ids[i][take[i]]].tolist())) for i in range(0, nq, max(1, nq // 2000))])
+        bal = ("; codes per rank and step: max %.3g / mean %.3g = %.3f; ranks a query's scored lists touch: %.2f of %d"
+               % (per_rank.max(), per_rank.mean(), per_rank.max() / per_rank.mean(), ranks_per_q.mean(), W))
+        assert int(per_rank[r]) == here, (per_rank[r], here)
+    print("world %d rank %d (%s, %s partition, %s): this rank's compute per step %.3f ms for %d queries -> %.2f M queries/s "
+          "aggregate if collectives were free; stages %s; scan kernel %s; codes scored here per step %d%s"
+          % (W, r, args.scaling, args.partition, name, t * 1e3, nq, nq / t / 1e6, st, g.last_scan_kernel(), here, bal),
+          flush=True)
 
 
 if __name__ == "__main__":

@@ -1,16 +1,23 @@
 #!/bin/bash
-# N ranks of bench.py on ONE GPU over gloo against the single-rank run of the same scaled corpus: labels and
+# N ranks of bench.py on ONE GPU over gloo against the single-rank run of the same corpus and batch: labels and
 # distance bits must agree (N <= 5: the box allows six processes on its GPU and the launcher counts).
-# usage: bash tools/rehearse_ranks.sh <N> [workload]
+# usage: bash tools/rehearse_ranks.sh <N> [workload] [extra bench args, e.g. --scaling strong]
 set -e
 cd "$(dirname "$0")/.."
-N=${1:-4}; W=${2:-synthetic-100M-pq16-nc131072-nprobe32}
+N=${1:-4}; W=${2:-synthetic-100M-pq16-nc131072-nprobe32}; shift; shift || true
+B=$(python - "$W" "$N" "$@" <<'PY'
+import sys; sys.path.insert(0, '.')
+import bench
+w, n = sys.argv[1], int(sys.argv[2])
+print(bench.STRONG_BATCH if "strong" in sys.argv[3:] else bench.WORKLOADS[w][7] * n)
+PY
+)
 mkdir -p gpurun_out
-python bench.py --gpus 1 --scale $N --steps 3 --warmup 1 --no-cpu-baseline --in-flight 1 --workload $W --dump gpurun_out/reh_1.npz > gpurun_out/reh_1.log 2>&1
-echo "[rehearse] single rank done"
+python bench.py --gpus 1 --batch $B --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --sustain-s 0 --in-flight 1 --workload $W --dump gpurun_out/reh_1.npz > gpurun_out/reh_1.log 2>&1
+echo "[rehearse] single rank done (batch $B)"
 IVFHNSW_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29517 \
-  bench.py --gpus $N --steps 3 --warmup 1 --workload $W --dump gpurun_out/reh_n.npz > gpurun_out/reh_n.log 2>&1
-echo "[rehearse] $N ranks done"
+  bench.py --gpus $N --steps 3 --warmup 1 --sustain-s 0 --workload $W --dump gpurun_out/reh_n.npz "$@" > gpurun_out/reh_n.log 2>&1
+echo "[rehearse] $N ranks done"; tail -1 gpurun_out/reh_n.log | cut -c1-600
 python - <<'PY'
 import numpy as np
 a = np.load('gpurun_out/reh_1.npz'); b = np.load('gpurun_out/reh_n.npz')
