@@ -91,7 +91,8 @@ class Corpus:
         self.owner = None
         if world > 1:
             sizes = np.diff(tb["offsets"].astype(np.int64))
-            self.owner = pkg_dist.partition_lists(tb["centroids"], sizes, world, partition)
+            load = pkg_dist.expected_list_load(sizes, self.counts, self.links)
+            self.owner = pkg_dist.partition_lists(tb["centroids"], sizes, world, partition, load=load)
         self.code_seed = seed + 7
         t0 = time.time()
         self.g = g = pkg.GpuIndex(local_rank)

@@ -351,7 +351,7 @@ bool scan_fused_supported(const IvfTables &t, bool short_segments)
 {
     static const int knob = [] {
         const char *e = getenv("IVFHNSW_SCAN_FUSED");
-        return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+        return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     if (knob == 0)
         return false;

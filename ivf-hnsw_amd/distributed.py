@@ -47,11 +47,26 @@ def query_slice(nq, rank, world):
     return min(rank * per, nq), min((rank + 1) * per, nq), per
 
 
-def partition_lists(centroids, list_sizes, world, method="spatial"):
+def expected_list_load(list_sizes, link_counts, links):
+    """Expected codes scored per query on every list, up to a constant: its size times how often it is probed.  A list
+    is probed when its centroid is among the nearest of a query, and queries fall where the data is, so the in-degree
+    of the centroid in the quantizer's own neighbour graph (the HNSW links the index already holds) estimates the
+    probe frequency -- small-norm "hub" centroids of non-negative descriptors are probed several times as often as
+    the average one, which a partition balanced by size alone turns into a 1.8x hot rank."""
+    n = len(list_sizes)
+    cnt = np.asarray(link_counts, np.int64)
+    lk = np.asarray(links).reshape(n, -1)
+    valid = np.arange(lk.shape[1])[None, :] < cnt[:, None]
+    indeg = np.bincount(lk[valid].astype(np.int64), minlength=n).astype(np.float64)
+    return np.asarray(list_sizes, np.float64) * (1.0 + indeg)
+
+
+def partition_lists(centroids, list_sizes, world, method="spatial", load=None):
     """Owner table for list-wise sharding (ivfhnsw_ivf_desc.list_owner): rank of every inverted list.
 
     "spatial": recursive bisection of the centroids along their principal direction, each cut placed so that both
-    sides hold the same number of CODES per rank (any world size: a node of w ranks splits w//2 : w - w//2).  Lists
+    sides carry the same LOAD per rank -- `load` (expected_list_load: size x probe frequency) when given, else the
+    number of codes (any world size: a node of w ranks splits w//2 : w - w//2).  Lists
     whose centroids are close end up on the same rank, so a query's probes -- the centroids nearest to it -- fall
     on few ranks; only those build and stage the query's table (the plan of every other rank is empty for it).
     How much that buys depends on the data: clustered descriptors (SIFT, DEEP) concentrate a query's probes,
@@ -65,7 +80,7 @@ def partition_lists(centroids, list_sizes, world, method="spatial"):
     if method != "spatial":
         raise ValueError("unknown partition method %r" % (method,))
     x_all = np.ascontiguousarray(centroids, np.float32)
-    sizes = np.asarray(list_sizes, np.float64)
+    sizes = np.asarray(list_sizes if load is None else load, np.float64)
     owner = np.zeros(nc, np.uint32)
     work = [(np.arange(nc, dtype=np.int64), 0, world)]
     while work:

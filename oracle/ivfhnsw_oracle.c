@@ -1007,6 +1007,71 @@ void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const u
     }
 }
 
+/* =============================================================================================
+ * Code book training, IndexIVF_HNSW.cpp:536-593 (train_pq): the reference hands residuals to
+ * faiss::ProductQuantizer::train, i.e. faiss's Clustering per sub-space.  faiss is absent from the
+ * reference tree (parity unpinned): restated here is the Lloyd iteration this repo's host classes run
+ * (ivf-hnsw_amd/csrc/host/faiss_min.cpp) and the device path must reproduce bit for bit --
+ *   assignment: the first nearest code word in fvec_L2sqr's SSE order, as compute_code finds it;
+ *   update    : mean of the assigned sub-vectors, the sum taken in point order in float, divided by
+ *               the count; a code word nothing was assigned to stays as it is.
+ * ============================================================================================= */
+void orc_pq_lloyd(size_t n, size_t d, size_t M, const float *x, size_t niter, float *centroids,
+                  uint8_t *out_assign)
+{
+    const size_t dsub = d / M;
+    uint8_t *assign = (uint8_t *)malloc(n * M + 1);
+    float *sum = (float *)malloc(256 * dsub * sizeof(float));
+    size_t *cnt = (size_t *)malloc(256 * sizeof(size_t));
+    for (size_t it = 0; it < niter; it++) {
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n; i++)
+            pq_compute_code(centroids, M, dsub, x + (size_t)i * d, assign + (size_t)i * M);
+        for (size_t m = 0; m < M; m++) {
+            memset(sum, 0, 256 * dsub * sizeof(float));
+            memset(cnt, 0, 256 * sizeof(size_t));
+            for (size_t i = 0; i < n; i++) {
+                const size_t c = assign[i * M + m];
+                cnt[c]++;
+                for (size_t j = 0; j < dsub; j++)
+                    sum[c * dsub + j] = sum[c * dsub + j] + x[i * d + m * dsub + j];
+            }
+            for (size_t c = 0; c < 256; c++)
+                if (cnt[c])
+                    for (size_t j = 0; j < dsub; j++)
+                        centroids[(m * 256 + c) * dsub + j] = sum[c * dsub + j] / (float)cnt[c];
+        }
+    }
+    if (out_assign)
+        memcpy(out_assign, assign, n * M);
+    free(assign);
+    free(sum);
+    free(cnt);
+}
+
+/* The d x d product of OPQ's Procrustes step, C[a][b] = sum_i X[i][a] * Y[i][b] (faiss OPQMatrix::train hands it
+ * to sgemm: order unspecified).  The contract here is the order the device's MFMA kernel produces: points in chunks
+ * of `chunk`, inside a chunk a fmaf chain in point order starting from 0 (v_mfma_f32_32x32x2_f32 is exactly that),
+ * the chunks' partial products added in chunk order. */
+void orc_xty(size_t n, size_t d, const float *X, const float *Y, size_t chunk, float *C)
+{
+#pragma omp parallel for schedule(static)
+    for (long aa = 0; aa < (long)d; aa++) {
+        const size_t a = (size_t)aa;
+        for (size_t b = 0; b < d; b++) {
+            float total = 0.0f;
+            for (size_t i0 = 0; i0 < n; i0 += chunk) {
+                const size_t i1 = i0 + chunk < n ? i0 + chunk : n;
+                float acc = 0.0f;
+                for (size_t i = i0; i < i1; i++)
+                    acc = fmaf(X[i * d + a], Y[i * d + b], acc);
+                total = i0 == 0 ? acc : total + acc;
+            }
+            C[a * d + b] = total;
+        }
+    }
+}
+
 /* IndexIVF_HNSW_Grouping.cpp:691-733 compute_alpha.  The per-point winner is maxheap.top() of
  * pair<-dist, pair<numerator, denominator>>: smallest dist, ties to the larger numerator, then denominator. */
 static float grouping_compute_alpha(size_t d, size_t nsubc, const float *centroid_vectors, const float *points,

@@ -134,6 +134,16 @@ void orc_search_batch(const orc_index *ix, size_t nq, size_t k, const float *x, 
 void orc_add_batch_encode(const orc_index *ix, size_t n, const float *x, const uint32_t *precomputed_idx,
                           uint32_t *out_idx, uint8_t *out_codes, uint8_t *out_norm_codes, float *out_norms);
 
+/* Code book training (IndexIVF_HNSW.cpp:536-593 train_pq -> faiss ProductQuantizer::train; faiss spec, parity
+ * unpinned): niter Lloyd iterations on n points x [n][d], centroids [M][256][d/M] in/out; assignment = first nearest
+ * code word in fvec_L2sqr's SSE order, update = mean with the sum taken in point order in float, empty clusters keep
+ * their code word.  out_assign (nullable) [n][M]: the last iteration's assignments. */
+void orc_pq_lloyd(size_t n, size_t d, size_t M, const float *x, size_t niter, float *centroids,
+                  uint8_t *out_assign);
+/* C[a][b] = sum_i X[i][a] * Y[i][b] in the order of the device's MFMA kernel: fmaf chains over chunks of `chunk`
+ * points, partial products added in chunk order (OPQ's Procrustes product). */
+void orc_xty(size_t n, size_t d, const float *X, const float *Y, size_t chunk, float *C);
+
 /* Grouping construction, IndexIVF_HNSW_Grouping.cpp:43-157 (add_group up to the distribution loops) for ONE
  * group: neighbour centroids = searchKnn(centroid, nsubc+1) with ix->efSearch minus the nearest (:47-62),
  * alpha (compute_alpha, :691-733), sub-centroids (:83-88), the sub-centroid of every point

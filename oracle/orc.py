@@ -81,6 +81,8 @@ def lib():
         L.orc_add_batch_encode.argtypes = [ip, sz, vp, vp, vp, vp, vp, vp]
         L.orc_add_group_encode.argtypes = [ip, sz, C.c_uint32, sz, vp, vp, vp, vp, vp, vp]
         L.orc_add_group_encode.restype = C.c_int
+        L.orc_pq_lloyd.argtypes = [sz, sz, sz, vp, sz, vp, vp]
+        L.orc_xty.argtypes = [sz, sz, vp, vp, sz, vp]
         L.orc_compute_centroid_norms.argtypes = [vp, vp]
         L.orc_compute_inter_centroid_dists.argtypes = [vp, sz, vp, vp]
         L.orc_rotate_quantizer.argtypes = [vp, vp]
@@ -121,6 +123,26 @@ def opq_apply(A, x):
     y = np.empty_like(x)
     lib().orc_opq_apply(_p(A), _p(x), x.size, _p(y))
     return y
+
+
+def pq_lloyd(x, M, centroids, niter=1):
+    """niter Lloyd iterations (the oracle's restatement of the code-book training step): (centroids, assign)."""
+    x = np.ascontiguousarray(x, np.float32)
+    n, d = x.shape
+    c = np.ascontiguousarray(centroids, np.float32).copy()
+    assert c.size == 256 * d
+    assign = np.empty((n, M), np.uint8)
+    lib().orc_pq_lloyd(n, d, M, _p(x), niter, _p(c), _p(assign))
+    return c, assign
+
+
+def xty(X, Y, chunk):
+    X = np.ascontiguousarray(X, np.float32)
+    Y = np.ascontiguousarray(Y, np.float32)
+    n, d = X.shape
+    C_ = np.empty((d, d), np.float32)
+    lib().orc_xty(n, d, _p(X), _p(Y), chunk, _p(C_))
+    return C_
 
 
 class Hnsw:
