@@ -218,6 +218,23 @@ int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, cons
                               float *out_alphas, uint32_t *out_subcentroid_idxs, uint8_t *out_codes,
                               uint8_t *out_norm_codes);
 
+/* ---- code-book training -------------------------------------------------------------------
+ *
+ * ivfhnsw_gpu_pq_train: the Lloyd iterations behind faiss::ProductQuantizer::train, which IndexIVF_HNSW::train_pq
+ * (IndexIVF_HNSW.cpp:536-593) and IndexIVF_HNSW_Grouping::train_pq (IndexIVF_HNSW_Grouping.cpp:486-560) call on
+ * residuals: niter iterations on n points x [n][d] (host), centroids [M][256][d/M] in and out (host).  Assignment =
+ * pq->compute_codes with the current code book (first nearest code word, faiss's SSE order), update = mean of the
+ * assigned sub-vectors with the sum taken in point order in float, code words nothing was assigned to stay.
+ * out_assign (nullable) [n][M]: the last iteration's assignments.  Needs no upload.  faiss's own clustering (its
+ * sampling, its random stream, its empty-cluster splits) is not reproduced: spec-level, parity unpinned.
+ *
+ * ivfhnsw_gpu_xty: C[a][b] = sum_i X[i][a] * Y[i][b] ([n][d] each, host; C [d][d]): the product behind the orthogonal
+ * Procrustes step of faiss::OPQMatrix::train, on the matrix cores (v_mfma_f32_32x32x2_f32).  Order: fmaf chains over
+ * chunks of IVFHNSW_XTY_CHUNK points, the chunks' partial products added in chunk order. */
+#define IVFHNSW_XTY_CHUNK 2048
+int ivfhnsw_gpu_pq_train(ivfhnsw_gpu *h, size_t n, size_t d, size_t M, const float *x, size_t niter, float *centroids,
+                         uint8_t *out_assign);
+int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const float *Y, float *C);
 
 enum ivfhnsw_stage {
     IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */

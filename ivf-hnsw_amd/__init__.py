@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_get_stage_ms", "ivfhnsw_gpu_reset_stage_ms", "ivfhnsw_gpu_last_scan_counts",
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
-    "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev",
+    "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
 )
 
 
@@ -102,6 +102,9 @@ def lib():
                                                   C.POINTER(C.c_uint32)]
         L.ivfhnsw_gpu_replay_stream_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32,
                                                     C.c_void_p]
+        L.ivfhnsw_gpu_pq_train.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_xty.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
@@ -311,6 +314,24 @@ class GpuIndex:
         _check(lib().ivfhnsw_gpu_encode_groups(self._h, G, nsubc, _ptr(cidx), _ptr(off), _ptr(x), efSearch, _ptr(nn),
                                                _ptr(alphas), _ptr(sub), _ptr(codes), _ptr(ncodes)))
         return nn, alphas, sub, codes, ncodes
+
+    def pq_train(self, x, M, centroids, niter=1):
+        """niter Lloyd iterations of ProductQuantizer::train on the device: (centroids [M, 256, d/M], assign [n, M])."""
+        x = _np(x, np.float32)
+        n, d = x.shape
+        c = _np(centroids, np.float32).copy().reshape(M, 256, d // M)
+        a = np.empty((n, M), np.uint8)
+        _check(lib().ivfhnsw_gpu_pq_train(self._h, n, d, M, _ptr(x), niter, _ptr(c), _ptr(a)))
+        return c, a
+
+    def xty(self, X, Y):
+        """X^T Y of OPQ's Procrustes step on the matrix cores ([n, d] each -> [d, d])."""
+        X = _np(X, np.float32)
+        Y = _np(Y, np.float32)
+        n, d = X.shape
+        out = np.empty((d, d), np.float32)
+        _check(lib().ivfhnsw_gpu_xty(self._h, n, d, _ptr(X), _ptr(Y), _ptr(out)))
+        return out
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

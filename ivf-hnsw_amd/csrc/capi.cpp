@@ -91,6 +91,7 @@ struct ivfhnsw_gpu {
     bool has_graph = false;
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
     DevBuf e_pqc, e_ntab, e_a, e_at, e_x, e_idx, e_dist, e_res, e_tmp, e_codes, e_ncodes;
+    DevBuf t_x, t_y, t_cb, t_assign, t_part, t_c; // training (pq_train, xty)
     DevBuf cg_q, cg_cidx, cg_ids, cg_dists, gc_nn, cg_cvn, cg_tab, cg_tab2, cg_off, cg_alpha2, cg_sub; // add_group
     size_t e_d = 0, e_M = 0;
     bool e_opq = false, has_codebooks = false;
@@ -343,7 +344,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     if (h->own_stream)
@@ -1029,6 +1030,55 @@ int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, cons
     return IVFHNSW_OK;
 }
 
+int ivfhnsw_gpu_pq_train(ivfhnsw_gpu *h, size_t n, size_t d, size_t M, const float *x, size_t niter, float *centroids,
+                         uint8_t *out_assign)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (n == 0 || d == 0 || M == 0 || d % M || d / M > 64 || !x || !centroids)
+        return fail(IVFHNSW_ERR_INVALID, "bad training arguments (n %zu, d %zu, M %zu)", n, d, M);
+    if ((rc = h->t_x.ensure(n * d * sizeof(float))) || (rc = h->t_cb.ensure(256 * d * sizeof(float))) ||
+        (rc = h->t_assign.ensure(n * M)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->t_x.p, x, n * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->t_cb.p, centroids, 256 * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    for (size_t it = 0; it < niter; it++) {
+        // assignment = pq->compute_codes with the current code book; update = means in point order
+        HIP_TRY(launch_pq_encode(h->stream, h->t_x.as<float>(), h->t_cb.as<float>(), h->t_assign.as<uint8_t>(), n, (int)d,
+                                 (int)M));
+        HIP_TRY(launch_lloyd_update(h->stream, h->t_x.as<float>(), h->t_assign.as<uint8_t>(), h->t_cb.as<float>(), n,
+                                    (int)d, (int)M));
+    }
+    HIP_TRY(hipMemcpyAsync(centroids, h->t_cb.p, 256 * d * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (out_assign && niter)
+        HIP_TRY(hipMemcpyAsync(out_assign, h->t_assign.p, n * M, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const float *Y, float *C)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (n == 0 || d == 0 || d > 4096 || !X || !Y || !C)
+        return fail(IVFHNSW_ERR_INVALID, "bad xty arguments (n %zu, d %zu)", n, d);
+    const size_t nchunks = (n + kXtyChunk - 1) / kXtyChunk;
+    if (nchunks > 65535)
+        return fail(IVFHNSW_ERR_INVALID, "xty: more than %d points", 65535 * kXtyChunk);
+    if ((rc = h->t_x.ensure(n * d * sizeof(float))) || (rc = h->t_y.ensure(n * d * sizeof(float))) ||
+        (rc = h->t_part.ensure(nchunks * d * d * sizeof(float))) || (rc = h->t_c.ensure(d * d * sizeof(float))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->t_x.p, X, n * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->t_y.p, Y, n * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(launch_xty(h->stream, h->t_x.as<float>(), h->t_y.as<float>(), h->t_part.as<float>(), h->t_c.as<float>(), n,
+                       (int)d));
+    HIP_TRY(hipMemcpyAsync(C, h->t_c.p, d * d * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
 static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
                             const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                             int64_t *d_labels, int64_t *d_out_keys);
@@ -1365,7 +1415,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

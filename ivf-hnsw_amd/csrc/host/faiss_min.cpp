@@ -10,6 +10,8 @@
 #include <faiss/index_io.h>
 #include <faiss/utils.h>
 
+#include <ivfhnsw_hip.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +21,24 @@
 #include <string>
 
 namespace faiss {
+
+namespace {
+
+// Training runs on the device (ivfhnsw_gpu_pq_train, ivfhnsw_gpu_xty): a handle for the duration of one call.
+// There is no host fallback: without a gfx950 device training fails, like every other device entry point.
+struct TrainDevice {
+    ivfhnsw_gpu *h = nullptr;
+    TrainDevice()
+    {
+        if (ivfhnsw_gpu_create(0, &h))
+            throw std::runtime_error(std::string("code-book training needs the device: ") + ivfhnsw_gpu_last_error());
+    }
+    ~TrainDevice() { ivfhnsw_gpu_destroy(h); }
+    TrainDevice(const TrainDevice &) = delete;
+    TrainDevice &operator=(const TrainDevice &) = delete;
+};
+
+} // namespace
 
 // ---------------------------------------------------------------------------------------------- heap
 void maxheap_heapify(size_t k, float *vals, long *ids, const float *x, const long *ids_in, size_t k0)
@@ -187,46 +207,21 @@ void ProductQuantizer::train(int n, const float *x) { train_iters(n, x, 25, fals
 
 void ProductQuantizer::train_iters(int n, const float *x, int niter, bool warm)
 {
-    // plain Lloyd iterations per sub-space, seeded with a random subset (construction side)
-    std::vector<int> perm((size_t)n);
-    std::vector<float> sum(ksub * dsub);
-    std::vector<size_t> cnt(ksub);
-    std::vector<uint32_t> assign((size_t)n);
-    for (size_t m = 0; m < M; m++) {
-        if (!warm) {
+    // Lloyd iterations per sub-space, seeded with a random subset; the iterations themselves run on the device
+    // (assignment = compute_codes with the current code book, update = means in point order: ivfhnsw_gpu_pq_train)
+    if (!warm) {
+        std::vector<int> perm((size_t)n);
+        for (size_t m = 0; m < M; m++) {
             rand_perm(perm.data(), (size_t)n, 1234 + (long)m);
             for (size_t c = 0; c < ksub; c++)
                 std::memcpy(get_centroids(m, c), x + (size_t)perm[c % (size_t)n] * d + m * dsub, dsub * sizeof(float));
         }
-        for (int it = 0; it < niter; it++) {
-#pragma omp parallel for
-            for (long i = 0; i < (long)n; i++) {
-                float best = INFINITY;
-                uint32_t arg = 0;
-                for (size_t c = 0; c < ksub; c++) {
-                    const float dist = fvec_L2sqr(x + (size_t)i * d + m * dsub, get_centroids(m, c), dsub);
-                    if (dist < best) {
-                        best = dist;
-                        arg = (uint32_t)c;
-                    }
-                }
-                assign[(size_t)i] = arg;
-            }
-            std::fill(sum.begin(), sum.end(), 0.f);
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (size_t i = 0; i < (size_t)n; i++) {
-                cnt[assign[i]]++;
-                for (size_t j = 0; j < dsub; j++)
-                    sum[assign[i] * dsub + j] += x[i * d + m * dsub + j];
-            }
-            for (size_t c = 0; c < ksub; c++)
-                if (cnt[c])
-                    for (size_t j = 0; j < dsub; j++)
-                        get_centroids(m, c)[j] = sum[c * dsub + j] / (float)cnt[c];
-        }
-        if (verbose)
-            printf("  PQ sub-quantizer %zu/%zu trained\n", m + 1, M);
     }
+    TrainDevice dev;
+    if (ivfhnsw_gpu_pq_train(dev.h, (size_t)n, d, M, x, (size_t)niter, centroids.data(), nullptr))
+        throw std::runtime_error(std::string("ivfhnsw_gpu_pq_train: ") + ivfhnsw_gpu_last_error());
+    if (verbose)
+        printf("  PQ: %zu sub-quantizers trained, %d iterations\n", M, niter);
 }
 
 // ---------------------------------------------------------------------------------------------- transforms
@@ -375,17 +370,15 @@ void OPQMatrix::train(long n_in, const float *x)
                 err += (double)(xr[e] - xd[e]) * (xr[e] - xd[e]);
             printf("  OPQ iteration %d/%d: quantisation error %.6g\n", it + 1, niter, err / (double)n);
         }
-        // C = X^T Y (d x d), C[a][b] = sum_i x_i[a] * y_i[b]
-        std::fill(c.begin(), c.end(), 0.0);
-#pragma omp parallel for
-        for (int a = 0; a < d; a++)
-            for (size_t i = 0; i < n; i++) {
-                const double xa = x[i * d + a];
-                const float *yi = xd.data() + i * d;
-                double *row = c.data() + (size_t)a * d;
-                for (int bb = 0; bb < d; bb++)
-                    row[bb] += xa * yi[bb];
-            }
+        // C = X^T Y (d x d), C[a][b] = sum_i x_i[a] * y_i[b]: on the matrix cores (ivfhnsw_gpu_xty)
+        {
+            TrainDevice dev;
+            std::vector<float> cf((size_t)d * d);
+            if (ivfhnsw_gpu_xty(dev.h, n, (size_t)d, x, xd.data(), cf.data()))
+                throw std::runtime_error(std::string("ivfhnsw_gpu_xty: ") + ivfhnsw_gpu_last_error());
+            for (size_t e = 0; e < cf.size(); e++)
+                c[e] = (double)cf[e];
+        }
         jacobi_svd(c, v, d); // columns of c: u_j * s_j
         // R = V U^T: R[i][k] = sum_j V[i][j] * U[k][j]
         for (int j = 0; j < d; j++) {

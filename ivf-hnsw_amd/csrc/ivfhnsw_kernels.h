@@ -138,6 +138,11 @@ hipError_t launch_pq_encode(hipStream_t s, const float *r, const float *cb, uint
 hipError_t launch_pq_decode(hipStream_t s, const uint8_t *codes, const float *cb, float *dec, size_t n, int d, int M);
 hipError_t launch_norm_codes(hipStream_t s, const float *rec, const float *ntab, uint8_t *norm_codes, float *norms_out,
                              size_t n, int d);
+// code-book training (kernels_train.hip): the update half of a Lloyd iteration (the assignment half is
+// launch_pq_encode), and OPQ's X^T Y on the matrix cores (chunks of kXtyChunk points, partials [nchunks][d][d])
+constexpr int kXtyChunk = 2048;
+hipError_t launch_lloyd_update(hipStream_t s, const float *x, const uint8_t *assign, float *cb, size_t n, int d, int M);
+hipError_t launch_xty(hipStream_t s, const float *X, const float *Y, float *partials, float *C, size_t n, int d);
 // Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-157)
 hipError_t launch_group_table(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
                               const uint32_t *nn, const float *alphas, const float *cv_in, float *out, size_t ngroups,

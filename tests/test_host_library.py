@@ -245,9 +245,10 @@ def test_reference_driver_binary_runs_on_this_library(tmp_path, driver, opq):
     assert abs(float(m.group(1)) - want) < 1e-6, (m.group(1), want)
 
 
-# ---------------------------------------------------------------------------------------------- training (host)
+# ---------------------------------------------------------------------------------------------- training
+@pytest.mark.gpu
 def test_opq_training_gives_a_rotation_that_helps(tmp_path):
-    """OPQMatrix::train (host): on points whose variance is mixed across sub-spaces the learnt matrix must be
+    """OPQMatrix::train (Lloyd iterations and X^T Y on the device, the d x d SVD on the host): on points whose variance is mixed across sub-spaces the learnt matrix must be
     orthonormal and the product quantizer trained behind it must beat the one trained on the raw points."""
     rng = np.random.default_rng(31)
     d, M, n = 32, 4, 4000
@@ -269,7 +270,7 @@ def test_opq_training_gives_a_rotation_that_helps(tmp_path):
 
 @pytest.mark.gpu
 def test_grouping_train_pq_writes_usable_code_books(tmp_path):
-    """IndexIVF_HNSW_Grouping::train_pq (assignment on the device, training on the host): the residual code book
+    """IndexIVF_HNSW_Grouping::train_pq (assignment and the Lloyd iterations on the device): the residual code book
     must quantise the training residuals far better than the points themselves, the norm code book must be 256
     finite values around the squared norms."""
     rng = np.random.default_rng(32)
