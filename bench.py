@@ -11,7 +11,8 @@ synthetic data: see tests/synth.py.  The same JSON line carries `secondary` resu
 centroids) and configs[2] (the 1B corpus at (64, 30000, 100)).
 
 N > 1: the SAME 1B corpus, its inverted lists sharded list-wise over the N ranks by an owner table
-(a balanced spatial partition of the centroids, ivf-hnsw_amd/distributed.py); every rank holds the replicated
+(--partition: c % N, or a load-balanced spatial partition of the centroids, ivf-hnsw_amd/distributed.py); every rank
+holds the replicated
 tables and graph.  The coarse walk is split over the ranks by query and all-gathered, every rank scans the lists
 it owns for ALL queries, and the packed (distance, scan position) keys are MIN-all-reduced over RCCL, the owner's
 labels MAX-all-reduced.
@@ -65,7 +66,7 @@ def log(*a):
 class Corpus:
     """Synthetic tables + graph of one workload and its device index (this rank's shard)."""
 
-    def __init__(self, pkg, synth, name, seed, dev, local_rank, rank=0, world=1, scale=1, partition="spatial", pkg_dist=None):
+    def __init__(self, pkg, synth, name, seed, dev, local_rank, rank=0, world=1, scale=1, partition="mod", pkg_dist=None):
         n_total, nc, d, M, self.nprobe, self.max_codes, self.ef, self.nq = WORKLOADS[name]
         n_total, nc = n_total * scale, nc * scale
         if n_total >= 2 ** 32:
@@ -175,7 +176,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
                     help="N > 1: weak = N x 10 k queries per step (per-GPU work fixed); strong = 80 k queries at every N")
     ap.add_argument("--batch", type=int, default=0, help="queries per step (overrides the workload's / the scaling mode's)")
-    ap.add_argument("--partition", choices=("spatial", "mod"), default="spatial", help="owner table of the list shards")
+    ap.add_argument("--partition", choices=("spatial", "mod"), default="mod",
+                    help="owner table of the list shards: c %% N, or the load-balanced spatial bisection (DESIGN.md 7)")
     ap.add_argument("--scale", type=int, default=1,
                     help="legacy weak scaling: corpus and centroid multiplier (round 1 ran the 100M workload x N)")
     ap.add_argument("--in-flight", type=int, default=2,

@@ -340,13 +340,17 @@ __global__ __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 } // namespace
 
-// Where the fused form is used (measured on MI355X, 1B codes, 10 k queries, profiles/r02_fused_ab.md):
-//   * sub-group plans (Grouping): 0.561 ms against 0.053 (tables) + 0.579 (scan_k1_short_kernel);
-//   * list shards of a multi-GPU index: every rank would otherwise build, write and stage the table of (nearly)
-//     every query of the N-times larger batch for 1/N of its codes;
-//   * one GPU, whole lists: NOT used -- 0.506 ms against 0.052 + 0.366: at 4 waves per SIMD the per-query chain
-//     (queue, plan, table, scan, reduce) of two workgroups per CU hides less than eight independent workgroups do.
-// IVFHNSW_SCAN_FUSED = 0 never, 1 always (where the shape is supported), unset = the rule above.
+// Where the fused form is used (measured on MI355X, 1B codes, profiles/r02_fused_ab.md): NOWHERE by default.
+//   * one GPU, whole lists: 0.506 ms against 0.052 (tables) + 0.366 (scan_k1_kernel);
+//   * one rank of eight list shards, 80 k queries: 0.971 ms against 0.262 + 0.476 -- and a rank holding HALF the codes
+//     of another takes the same time: the kernel is bound by its per-query dependent chain (queue -> plan header ->
+//     query -> table -> barrier -> plan -> one scan iteration -> reduction, ~6 us) with only two workgroups per CU to
+//     overlap it, where the plain scan keeps eight independent workgroups per CU in flight;
+//   * sub-group plans (Grouping): 0.561 ms against 0.053 + 0.579 for scan_k1_short_kernel -- a gain that came from the
+//     bitmap segment lookup, not from the fusion: scan_k1_bitmap_kernel (kernels_search.hip) has the lookup without it.
+// Kept as an exact, tested form behind IVFHNSW_SCAN_FUSED=1 (the differential suite passes with it forced on): what
+// would make it pay is a software pipeline over queries (next query's header, vector and plan in flight during the
+// current scan).
 bool scan_fused_supported(const IvfTables &t, bool short_segments)
 {
     static const int knob = [] {
@@ -358,7 +362,8 @@ bool scan_fused_supported(const IvfTables &t, bool short_segments)
     const bool shape = (t.M == 16 && (t.dsub == 8 || t.dsub == 6)) || (t.M == 8 && (t.dsub == 16 || t.dsub == 12));
     if (!shape)
         return false;
-    return knob == 1 || short_segments || t.shard_world > 1;
+    (void)short_segments;
+    return knob == 1;
 }
 
 hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,

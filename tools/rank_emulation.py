@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--partition", choices=("spatial", "mod"), default="spatial")
+    ap.add_argument("--partition", choices=("spatial", "mod"), default="mod")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
