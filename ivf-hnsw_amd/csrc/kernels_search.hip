@@ -568,6 +568,187 @@ __global__ __launch_bounds__(256) void scan_k1_short_kernel(const uint8_t *__res
     }
 }
 
+// The scan for SHORT segments, third form (Grouping: a sub-group holds ~16 codes at the reference's nsubc 64).
+// scan_k1_kernel deals positions to lanes but searches the segment of every position in the LDS plan;
+// scan_k1_short_kernel gives a lane group to every segment and leaves half the lanes idle -- and the scan is bound by
+// LDS instruction issue, so idle lanes cost as much as busy ones.  Here positions are dealt to lanes one code each
+// AND the segment comes from a bitmap: one bit per position of the plan chunk, set where a segment starts, plus the
+// number of starts before every 64-position word.  A wavefront's 64 positions share a word, so
+//     segment = pref[word] + popcount(mask[word] & lanes_up_to_mine) - 1
+// is one broadcast LDS read and two v_mbcnt.  Chunks of <= 256 segments and <= 8192 positions: 23 KB of LDS per
+// workgroup, six workgroups per CU.
+constexpr int BM_SEGCAP = 256;
+constexpr int BM_SPANCAP = 8192;
+constexpr int BM_SPANW = BM_SPANCAP / 64;
+
+template <int CS, int U>
+__global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__restrict__ codes,
+                                                             const uint8_t *__restrict__ norm_codes,
+                                                             const float *__restrict__ luts,
+                                                             const float *__restrict__ norm_table,
+                                                             const Seg *__restrict__ segs,
+                                                             const uint32_t *__restrict__ lpos,
+                                                             const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
+                                                             unsigned long long *__restrict__ keys)
+{
+    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
+    __shared__ float s_norm[256];
+    __shared__ __attribute__((aligned(16))) Seg s_seg[BM_SEGCAP];
+    __shared__ uint32_t s_lpos[BM_SEGCAP + 1];
+    __shared__ unsigned long long s_mask[BM_SPANW];
+    __shared__ uint32_t s_pref[BM_SPANW];
+    __shared__ uint32_t s_wtot[4];
+    __shared__ unsigned long long s_red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x / nsplit;
+    const int split = blockIdx.x - q * nsplit;
+    const PlanHdr h = hdr[q];
+    if (h.total == 0)
+        return;
+    uint32_t per = (h.total + nsplit - 1) / nsplit;
+    per = (per + 255u) & ~255u;
+    const uint32_t lo = min((uint32_t)split * per, h.total);
+    const uint32_t hi = min(lo + per, h.total);
+    if (lo >= hi)
+        return;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
+        float4 *dst = reinterpret_cast<float4 *>(s_lut);
+        for (int i = tid; i < CS * 64; i += 256)
+            dst[i] = src[i];
+        s_norm[tid] = norm_table[tid];
+    }
+    const Seg *sq = segs + (size_t)q * max_seg;
+    const uint32_t *lq = lpos + (size_t)q * max_seg;
+    unsigned long long best = kKeyInit;
+
+    // first segment of this split: the last one starting at or before lo
+    uint32_t cs = 0;
+    if (lo > 0) {
+        uint32_t a = 0, b = h.nseg - 1;
+        while (a < b) {
+            const uint32_t mid = (a + b + 1) >> 1;
+            if (lq[mid] <= lo)
+                a = mid;
+            else
+                b = mid - 1;
+        }
+        cs = a;
+    }
+    while (cs < h.nseg) {
+        const uint32_t cl = lq[cs];
+        if (cl >= hi)
+            break;
+        // as many segments as fit the plan buffer AND the bitmap's span; one oversized segment goes alone
+        uint32_t cn = min((uint32_t)BM_SEGCAP, h.nseg - cs);
+        {
+            const uint32_t end_all = (cs + cn == h.nseg) ? h.total : lq[cs + cn];
+            if (end_all - cl > (uint32_t)BM_SPANCAP) {
+                uint32_t a = 1, b = cn > 1 ? cn - 1 : 1; // largest count whose end stays inside the span (or 1)
+                while (a < b) {
+                    const uint32_t mid = (a + b + 1) >> 1;
+                    if (lq[cs + mid] - cl <= (uint32_t)BM_SPANCAP)
+                        a = mid;
+                    else
+                        b = mid - 1;
+                }
+                cn = a;
+            }
+        }
+        const uint32_t ch = (cs + cn == h.nseg) ? h.total : lq[cs + cn];
+        const bool single = ch - cl > (uint32_t)BM_SPANCAP; // cn == 1: every position belongs to segment 0
+        const uint32_t nwords = single ? 0u : (ch - cl + 63) >> 6;
+        __syncthreads(); // previous chunk fully consumed (and the table staged, first time)
+        for (uint32_t i = tid; i < cn; i += 256) {
+            s_seg[i] = sq[cs + i];
+            s_lpos[i] = lq[cs + i];
+        }
+        if (tid < (int)nwords)
+            s_mask[tid] = 0ull;
+        __syncthreads();
+        if (!single) {
+            uint32_t *m32 = reinterpret_cast<uint32_t *>(s_mask);
+            for (uint32_t i = tid; i < cn; i += 256) {
+                const uint32_t r = s_lpos[i] - cl;
+                atomicOr(&m32[r >> 5], 1u << (r & 31));
+            }
+            __syncthreads();
+            // starts before every word (at most 128 words: waves 0 and 1 scan, two totals)
+            const uint32_t cnt = tid < (int)nwords ? (uint32_t)__popcll(s_mask[tid]) : 0u;
+            const uint32_t inc = wave_incl_scan(cnt, lane);
+            if (lane == 63)
+                s_wtot[wave] = inc;
+            __syncthreads();
+            if (tid < (int)nwords)
+                s_pref[tid] = (wave ? s_wtot[0] : 0u) + inc - cnt;
+            __syncthreads();
+        }
+        const uint32_t b0 = max(cl, lo), b1 = min(ch, hi);
+        if (b0 < b1) {
+            for (uint32_t rbase = (b0 - cl) & ~63u; rbase < b1 - cl; rbase += 256 * U) {
+                CodeRegs<CS> w[U];
+                uint32_t nb[U], vp[U];
+                float ct[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t r = rbase + u * 256 + tid;
+                    const uint32_t p = cl + r;
+                    ok[u] = p >= b0 && p < b1;
+                    const uint32_t wi = __builtin_amdgcn_readfirstlane(r >> 6);
+                    if (wi * 64u < b1 - cl) { // wave-uniform
+                        uint32_t sgi = 0;
+                        if (!single) {
+                            const unsigned long long mw = s_mask[wi];
+                            const uint32_t below =
+                                __builtin_amdgcn_mbcnt_hi((uint32_t)(mw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw, 0u));
+                            sgi = s_pref[wi] + below + (uint32_t)((mw >> lane) & 1ull) - 1u;
+                        }
+                        if (ok[u]) {
+                            const Seg sg = s_seg[sgi];
+                            const uint32_t off = p - s_lpos[sgi];
+                            const uint32_t gi = sg.start + off;
+                            code_fetch<CS>(codes, gi, CS, s_lut, w[u]);
+                            nb[u] = norm_codes[gi];
+                            vp[u] = sg.vpos + off;
+                            ct[u] = sg.cterm;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (ok[u]) {
+                        const float sum = code_sum<CS>(s_lut, w[u]);
+                        const float tt = __fadd_rn(ct[u], s_norm[nb[u]]);
+                        const float dist = __fsub_rn(tt, __fmul_rn(2.0f, sum));
+                        if (dist < FLT_MAX) {
+                            const unsigned long long key =
+                                ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | vp[u];
+                            best = key < best ? key : best;
+                        }
+                    }
+                }
+            }
+        }
+        cs += cn;
+    }
+    best = wave_min_u64(best);
+    if (lane == 0)
+        s_red[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long m = s_red[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++)
+            m = s_red[i] < m ? s_red[i] : m;
+        if (nsplit == 1)
+            keys[q] = m;
+        else if (m < kKeyInit)
+            atomicMin(&keys[q], m);
+    }
+}
+
 // which scan kernel the last launch_scan of this thread chose (reported by bench.py next to its roofline)
 static thread_local const char *g_scan_kernel_name = "";
 const char *last_scan_kernel_name() { return g_scan_kernel_name; }
@@ -595,6 +776,17 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         const char *e = getenv("IVFHNSW_SCAN_SHORT");
         return !(e && atoi(e) == 0);
     }();
+    // IVFHNSW_SCAN_SHORT: 2 (default) = bitmap form, 1 = lane group per segment, 0 = the position form with its search
+    static const int short_form = [] {
+        const char *e = getenv("IVFHNSW_SCAN_SHORT");
+        return (e && *e) ? atoi(e) : 2;
+    }();
+    if (short_form >= 2 && seg_len_hint > 0 && seg_len_hint <= 48) {
+        g_scan_kernel_name = "scan_k1_bitmap_kernel";
+        hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table,
+                           segs, lpos, hdr, max_seg, nsplit, k64);
+        return hipGetLastError();
+    }
     if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
         g_scan_kernel_name = "scan_k1_short_kernel";
 #define IVFHNSW_SCAN_SHORT(GG)                                                                                        \
