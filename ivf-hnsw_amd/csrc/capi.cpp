@@ -83,7 +83,7 @@ struct ivfhnsw_gpu {
     IvfTables t{};
     bool has_ivf = false;
     uint64_t n_local = 0;
-    DevBuf g_alpha, g_nn, g_sizes, g_inter, g_tiles, g_toff;
+    DevBuf g_alpha, g_nn, g_sizes, g_inter;
     GroupTables g{};
     bool has_group = false;
     DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms;
@@ -98,7 +98,7 @@ struct ivfhnsw_gpu {
 
     // per-batch workspace
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
-        w_slen, w_counter, w_tpos;
+        w_slen, w_counter;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
 
@@ -342,9 +342,9 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->g_tiles, &h->g_toff, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tpos, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     if (h->own_stream)
@@ -507,42 +507,6 @@ int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alpha
     h->g.nn_idx = h->g_nn.as<uint32_t>();
     h->g.sub_sizes = h->g_sizes.as<uint32_t>();
     h->g.inter_dists = h->g_inter.as<float>();
-    h->g.tiles = nullptr;
-    h->g.toff16 = nullptr;
-    // Sub-group tiles for the short-segment scan (GroupTables::tiles): a second copy of the codes and norm codes,
-    // 17.5 instead of 17 bytes per code -- HBM capacity spent on lines: 288 GB hold it four times over at 1B vectors.
-    // IVFHNSW_GROUP_TILES=0 keeps the flat arrays only.
-    {
-        static const bool tiles_on = [] {
-            const char *e = getenv("IVFHNSW_GROUP_TILES");
-            return !(e && *e && atoi(e) == 0);
-        }();
-        const int M = h->t.M;
-        if (tiles_on && (M == 4 || M == 8 || M == 16 || M == 32)) {
-            std::vector<uint32_t> loff(nc), toff(nc, kNotOwned);
-            HIP_TRY(hipMemcpy(loff.data(), h->loff.p, nc * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            uint64_t units = 0;
-            for (size_t c = 0; c < nc; c++) {
-                if (loff[c] == kNotOwned)
-                    continue;
-                toff[c] = (uint32_t)units;
-                for (size_t j = 0; j < nsubc; j++)
-                    units += tile_units(subgroup_sizes[c * nsubc + j], M);
-                if (units >= 0xffffffffull)
-                    break;
-            }
-            if (units < 0xffffffffull) {
-                if ((rc = upload(h->g_toff, toff.data(), nc * sizeof(uint32_t))))
-                    return rc;
-                if ((rc = h->g_tiles.ensure((size_t)units * 16 + 16)))
-                    return rc;
-                h->g.toff16 = h->g_toff.as<uint32_t>();
-                HIP_TRY(launch_build_tiles(h->stream, h->t, h->g, h->g_tiles.as<uint8_t>()));
-                HIP_TRY(hipStreamSynchronize(h->stream));
-                h->g.tiles = h->g_tiles.as<uint8_t>();
-            }
-        }
-    }
     h->has_group = true;
     return IVFHNSW_OK;
 }
@@ -1215,12 +1179,10 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         if (h->has_group) {
             if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
                 return rc;
-            if (h->g.tiles && (rc = h->w_tpos.ensure(nq * (size_t)max_seg * sizeof(uint32_t))))
-                return rc;
             HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
                                          p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                                          h->w_hdr.as<PlanHdr>(), max_seg, h->w_keys.as<uint64_t>(), (int)k,
-                                         h->w_qsd.as<float>(), h->w_tpos.as<uint32_t>()));
+                                         h->w_qsd.as<float>()));
         } else {
             HIP_TRY(launch_plan_ivf(h->stream, h->t, cid, cd, (int)nq, nprobe, p->max_codes, h->w_segs.as<Seg>(),
                                     h->w_lpos.as<uint32_t>(), h->w_hdr.as<PlanHdr>(), max_seg,
@@ -1267,8 +1229,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
             HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                                 h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
                                 heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
-                                heap ? kHeapStreamCap : 0, seg_hint, h->has_group ? h->g.tiles : nullptr,
-                                h->has_group && h->g.tiles ? h->w_tpos.as<uint32_t>() : nullptr));
+                                heap ? kHeapStreamCap : 0, seg_hint));
             h->last_scan_kernel = last_scan_kernel_name();
         }
     }
@@ -1452,9 +1413,9 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     if (!h || !bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
-                           &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->g_tiles, &h->g_toff, &h->q_counts, &h->q_links,
+                           &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tpos, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

@@ -58,19 +58,7 @@ struct GroupTables {
     const uint32_t *nn_idx;
     const uint32_t *sub_sizes;
     const float *inter_dists;
-    // Sub-group tiles (the layout scan_k1_bitmap_kernel reads; NULL = flat arrays only).  Every sub-group of every owned
-    // list is one 16-byte-aligned run: its n codes, padded to 16 bytes, then its n norm bytes, padded to 16 bytes --
-    // tile_units(n) 16-byte units.  The flat codes / norm_codes arrays keep two streams per segment (a 12..16-byte
-    // run of norm bytes costs a whole 128-byte line of its own); a tile keeps them on the lines the codes touch anyway.
-    const uint8_t *tiles;
-    const uint32_t *toff16; // [nc] first 16-byte unit of list c's tiles (kNotOwned for lists of other shards)
 };
-__host__ __device__ inline uint32_t tile_units(uint32_t n, int code_size)
-{
-    return (n * (uint32_t)code_size + 15u) / 16u + (n + 15u) / 16u;
-}
-// flat codes / norm codes -> tiles, one workgroup per list
-hipError_t launch_build_tiles(hipStream_t s, const IvfTables &t, const GroupTables &g, uint8_t *tiles);
 
 struct GraphTables {
     uint32_t n;
@@ -106,14 +94,12 @@ hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *co
 hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
                                 const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
                                 int nprobe, uint64_t max_codes, int do_pruning, Seg *segs, uint32_t *lpos,
-                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *qsd_scratch,
-                                uint32_t *tpos = nullptr); // [nq*max_seg] tile unit of every segment (g.tiles only)
+                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *qsd_scratch);
 // the ADC loop (IndexIVF_HNSW.cpp:282-289 / IndexIVF_HNSW_Grouping.cpp:321-333)
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys,
                        uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0,
-                       int seg_len_hint = 0, // expected codes per plan segment (0 = unknown): picks the scan form
-                       const uint8_t *tiles = nullptr, const uint32_t *tpos = nullptr); // sub-group tiles (bitmap form)
+                       int seg_len_hint = 0); // expected codes per plan segment (0 = unknown): picks the scan form
 // table + scan in one persistent kernel, code book in registers (kernels_scan2.hip); k = 1, PQ16 / PQ8 at d = 128, 96
 bool scan_fused_supported(const IvfTables &t, bool short_segments);
 hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
                                                            Seg *__restrict__ segs, uint32_t *__restrict__ lpos,
                                                            PlanHdr *__restrict__ hdr, int max_seg,
                                                            unsigned long long *__restrict__ keys, int k,
-                                                           float *__restrict__ scratch, uint32_t *__restrict__ tpos)
+                                                           float *__restrict__ scratch)
 {
     extern __shared__ __attribute__((aligned(16))) float s_q[]; // query[d] | dist[64]
     const int lane = threadIdx.x;
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
     int row = 0;
     Seg *sq = segs + (size_t)q * max_seg;
     uint32_t *lq = lpos + (size_t)q * max_seg;
-    uint32_t *tq = tpos ? tpos + (size_t)q * max_seg : nullptr;
     for (int i = 0; i < nprobe; i++) {
         const uint32_t c = qc[i];
         if (c >= t.nc)
@@ -128,7 +127,6 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
         const float alpha = g.alphas[c];
         const float oma = __fsub_rn(1.0f, alpha);
         const float term1 = __fmul_rn(oma, __fsub_rn(qd[i], t.centroid_norms[c]));
-        uint32_t list_tu = 0; // tile units of this list before the current chunk of sub-groups
         const uint32_t lo_c = t.loff[c];
         const bool owned = lo_c != kNotOwned;
         uint32_t list_off = 0; // codes of this list before the current chunk of sub-groups
@@ -177,8 +175,6 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
             }
             const uint32_t in_sz = wave_incl_scan(sz, lane);
             const uint32_t in_sc = wave_incl_scan(scanned ? sz : 0u, lane);
-            const uint32_t tu = tq ? tile_units(sz, t.M) : 0u;
-            const uint32_t in_tu = tq ? wave_incl_scan(tu, lane) : 0u;
             const unsigned long long m = __ballot(scanned);
             const uint32_t rank_sc = __popcll(m & ((1ull << lane) - 1ull));
             if (scanned && owned) {
@@ -189,11 +185,7 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
                 sg.cterm = cterm;
                 sq[ns + rank_sc] = sg;
                 lq[ns + rank_sc] = nl + (in_sc - sz);
-                if (tq)
-                    tq[ns + rank_sc] = g.toff16[c] + list_tu + (in_tu - tu);
             }
-            if (tq)
-                list_tu += __shfl(in_tu, 63, 64);
             const uint32_t tot_sz = __shfl(in_sz, 63, 64), tot_sc = __shfl(in_sc, 63, 64);
             list_off += tot_sz;
             ncode += tot_sc;
@@ -218,42 +210,13 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
 hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
                                 const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
                                 int nprobe, uint64_t max_codes, int do_pruning, Seg *segs, uint32_t *lpos,
-                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *scratch, uint32_t *tpos)
+                                PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *scratch)
 {
     if (nq == 0)
         return hipSuccess;
     hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), (t.d + 64) * sizeof(float), s, t, g, gr, xq, coarse_ids,
                        coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr, max_seg,
-                       reinterpret_cast<unsigned long long *>(keys), k, scratch, g.tiles ? tpos : nullptr);
-    return hipGetLastError();
-}
-
-// flat -> tiles: one workgroup per list; sub-group s of list c starts tile_units(sizes before it) after toff16[c]
-__global__ __launch_bounds__(256) void build_tiles_kernel(IvfTables t, GroupTables g, uint8_t *__restrict__ tiles)
-{
-    for (uint32_t c = blockIdx.x; c < t.nc; c += gridDim.x) {
-        const uint32_t l0 = t.loff[c];
-        if (l0 == kNotOwned)
-            continue;
-        uint32_t code0 = l0, unit0 = g.toff16[c];
-        for (int sub = 0; sub < g.nsubc; sub++) {
-            const uint32_t n = g.sub_sizes[(size_t)c * g.nsubc + sub];
-            uint8_t *tp = tiles + (size_t)unit0 * 16;
-            const uint32_t cbytes = n * (uint32_t)t.M, cpad = (cbytes + 15u) & ~15u, npad = (n + 15u) & ~15u;
-            const uint8_t *src = t.codes + (size_t)code0 * t.M;
-            for (uint32_t b = threadIdx.x * 4; b < cpad; b += 256 * 4) // code_size is a multiple of 4
-                *reinterpret_cast<uint32_t *>(tp + b) = b < cbytes ? *reinterpret_cast<const uint32_t *>(src + b) : 0u;
-            for (uint32_t b = threadIdx.x; b < npad; b += 256)
-                tp[cpad + b] = b < n ? t.norm_codes[code0 + b] : (uint8_t)0;
-            code0 += n;
-            unit0 += tile_units(n, t.M);
-        }
-    }
-}
-
-hipError_t launch_build_tiles(hipStream_t s, const IvfTables &t, const GroupTables &g, uint8_t *tiles)
-{
-    hipLaunchKernelGGL(build_tiles_kernel, dim3(256 * 16), dim3(256), 0, s, t, g, tiles);
+                       reinterpret_cast<unsigned long long *>(keys), k, scratch);
     return hipGetLastError();
 }
 

@@ -581,7 +581,7 @@ constexpr int BM_SEGCAP = 256;
 constexpr int BM_SPANCAP = 8192;
 constexpr int BM_SPANW = BM_SPANCAP / 64;
 
-template <int CS, int U, bool TILES>
+template <int CS, int U>
 __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__restrict__ codes,
                                                              const uint8_t *__restrict__ norm_codes,
                                                              const float *__restrict__ luts,
@@ -589,12 +589,8 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
                                                              const Seg *__restrict__ segs,
                                                              const uint32_t *__restrict__ lpos,
                                                              const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                             unsigned long long *__restrict__ keys,
-                                                             const uint8_t *__restrict__ tiles,
-                                                             const uint32_t *__restrict__ tpos)
+                                                             unsigned long long *__restrict__ keys)
 {
-    // TILES: codes and norm bytes of a segment come from its tile (GroupTables::tiles): `start` of the staged plan
-    // entries is then the tile's first 16-byte unit instead of the flat code index
     __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
     __shared__ float s_norm[256];
     __shared__ __attribute__((aligned(16))) Seg s_seg[BM_SEGCAP];
@@ -625,7 +621,6 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
     }
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t *lq = lpos + (size_t)q * max_seg;
-    const uint32_t *tq = TILES ? tpos + (size_t)q * max_seg : nullptr;
     unsigned long long best = kKeyInit;
 
     // first segment of this split: the last one starting at or before lo
@@ -666,10 +661,7 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
         const uint32_t nwords = single ? 0u : (ch - cl + 63) >> 6;
         __syncthreads(); // previous chunk fully consumed (and the table staged, first time)
         for (uint32_t i = tid; i < cn; i += 256) {
-            Seg sg = sq[cs + i];
-            if constexpr (TILES)
-                sg.start = tq[cs + i];
-            s_seg[i] = sg;
+            s_seg[i] = sq[cs + i];
             s_lpos[i] = lq[cs + i];
         }
         if (tid < (int)nwords)
@@ -716,15 +708,9 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
                         if (ok[u]) {
                             const Seg sg = s_seg[sgi];
                             const uint32_t off = p - s_lpos[sgi];
-                            if constexpr (TILES) {
-                                const uint8_t *tp = tiles + (size_t)sg.start * 16;
-                                code_fetch<CS>(tp, off, CS, s_lut, w[u]);
-                                nb[u] = tp[((sg.len * (uint32_t)CS + 15u) & ~15u) + off];
-                            } else {
-                                const uint32_t gi = sg.start + off;
-                                code_fetch<CS>(codes, gi, CS, s_lut, w[u]);
-                                nb[u] = norm_codes[gi];
-                            }
+                            const uint32_t gi = sg.start + off;
+                            code_fetch<CS>(codes, gi, CS, s_lut, w[u]);
+                            nb[u] = norm_codes[gi];
                             vp[u] = sg.vpos + off;
                             ct[u] = sg.cterm;
                         }
@@ -781,7 +767,7 @@ static int scan_rep_choice()
 template <int CS>
 static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
                                  const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
-                                 uint64_t *keys, int seg_len_hint, const uint8_t *tiles, const uint32_t *tpos)
+                                 uint64_t *keys, int seg_len_hint)
 {
     dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
@@ -796,15 +782,9 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         return (e && *e) ? atoi(e) : 2;
     }();
     if (short_form >= 2 && seg_len_hint > 0 && seg_len_hint <= 48) {
-        if (tiles && tpos) {
-            g_scan_kernel_name = "scan_k1_bitmap_kernel (tiles)";
-            hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4, true>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts,
-                               t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, tiles, tpos);
-        } else {
-            g_scan_kernel_name = "scan_k1_bitmap_kernel";
-            hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4, false>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts,
-                               t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, nullptr, nullptr);
-        }
+        g_scan_kernel_name = "scan_k1_bitmap_kernel";
+        hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table,
+                           segs, lpos, hdr, max_seg, nsplit, k64);
         return hipGetLastError();
     }
     if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
@@ -867,8 +847,7 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
 
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys, uint64_t *stream,
-                       uint32_t *stream_len, uint32_t stream_cap, int seg_len_hint, const uint8_t *tiles,
-                       const uint32_t *tpos)
+                       uint32_t *stream_len, uint32_t stream_cap, int seg_len_hint)
 {
     if (nq == 0)
         return hipSuccess;
@@ -877,10 +856,10 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
         return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys, stream, stream_len, stream_cap);
     }
     switch (t.M) {
-    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, tiles, tpos);
-    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, tiles, tpos);
-    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, tiles, tpos);
-    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, tiles, tpos);
+    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
     default: {
         // any other multiple of 4 (IndexIVF_HNSW.cpp:805): the run-time form, table in dynamic LDS
         const size_t shm = (size_t)t.M * 1024;
