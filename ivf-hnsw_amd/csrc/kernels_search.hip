@@ -575,11 +575,10 @@ __global__ __launch_bounds__(256) void scan_k1_short_kernel(const uint8_t *__res
 // AND the segment comes from a bitmap: one bit per position of the plan chunk, set where a segment starts, plus the
 // number of starts before every 64-position word.  A wavefront's 64 positions share a word, so
 //     segment = pref[word] + popcount(mask[word] & lanes_up_to_mine) - 1
-// is one broadcast LDS read and two v_mbcnt.  Chunks of <= 128 segments and <= 4096 positions keep the workgroup at
-// 19.5 KB of LDS, eight workgroups per CU: the waves wait on memory two thirds of the time (SQ_WAIT_ANY), not on the
-// LDS as the whole-list scan does, so residency is what the chunk size is chosen for.
-constexpr int BM_SEGCAP = 128;
-constexpr int BM_SPANCAP = 4096;
+// is one broadcast LDS read and two v_mbcnt.  Chunks of <= 256 segments and <= 8192 positions: 23 KB of LDS per
+// workgroup, six workgroups per CU.
+constexpr int BM_SEGCAP = 256;
+constexpr int BM_SPANCAP = 8192;
 constexpr int BM_SPANW = BM_SPANCAP / 64;
 
 // The staged plan entry of a segment is 8 bytes: (start - first position, cterm).  A lane at position p then needs
@@ -684,7 +683,7 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
                 atomicOr(&m32[r >> 5], 1u << (r & 31));
             }
             __syncthreads();
-            // starts before every word (at most 64 words: wave 0 scans)
+            // starts before every word (at most 128 words: waves 0 and 1 scan, two totals)
             const uint32_t cnt = tid < (int)nwords ? (uint32_t)__popcll(s_mask[tid]) : 0u;
             const uint32_t inc = wave_incl_scan(cnt, lane);
             if (lane == 63)
