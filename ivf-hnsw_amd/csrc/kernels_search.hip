@@ -581,11 +581,7 @@ constexpr int BM_SEGCAP = 256;
 constexpr int BM_SPANCAP = 8192;
 constexpr int BM_SPANW = BM_SPANCAP / 64;
 
-// The staged plan entry of a segment is 8 bytes: (start - first position, cterm).  A lane at position p then needs
-// ONE ds_read_b64 per code next to the 17 table gathers -- the kernel is bound by LDS issue, a 16-byte Seg plus its
-// position word cost five gather-equivalents where this costs two.  SHARDED: the global scan position differs from the
-// local one by a per-segment offset (one more word); on a single GPU they are the same number.
-template <int CS, int U, bool SHARDED>
+template <int CS, int U>
 __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__restrict__ codes,
                                                              const uint8_t *__restrict__ norm_codes,
                                                              const float *__restrict__ luts,
@@ -597,8 +593,7 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
 {
     __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
     __shared__ float s_norm[256];
-    __shared__ __attribute__((aligned(8))) uint2 s_rec[BM_SEGCAP]; // (start - lpos, cterm bits)
-    __shared__ uint32_t s_vd[SHARDED ? BM_SEGCAP : 1];              // vpos - lpos
+    __shared__ __attribute__((aligned(16))) Seg s_seg[BM_SEGCAP];
     __shared__ uint32_t s_lpos[BM_SEGCAP + 1];
     __shared__ unsigned long long s_mask[BM_SPANW];
     __shared__ uint32_t s_pref[BM_SPANW];
@@ -666,12 +661,8 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
         const uint32_t nwords = single ? 0u : (ch - cl + 63) >> 6;
         __syncthreads(); // previous chunk fully consumed (and the table staged, first time)
         for (uint32_t i = tid; i < cn; i += 256) {
-            const Seg sg = sq[cs + i];
-            const uint32_t lp = lq[cs + i];
-            s_rec[i] = make_uint2(sg.start - lp, __float_as_uint(sg.cterm));
-            if constexpr (SHARDED)
-                s_vd[i] = sg.vpos - lp;
-            s_lpos[i] = lp;
+            s_seg[i] = sq[cs + i];
+            s_lpos[i] = lq[cs + i];
         }
         if (tid < (int)nwords)
             s_mask[tid] = 0ull;
@@ -715,15 +706,13 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
                             sgi = s_pref[wi] + below + (uint32_t)((mw >> lane) & 1ull) - 1u;
                         }
                         if (ok[u]) {
-                            const uint2 rec = s_rec[sgi];
-                            const uint32_t gi = p + rec.x;
+                            const Seg sg = s_seg[sgi];
+                            const uint32_t off = p - s_lpos[sgi];
+                            const uint32_t gi = sg.start + off;
                             code_fetch<CS>(codes, gi, CS, s_lut, w[u]);
                             nb[u] = norm_codes[gi];
-                            if constexpr (SHARDED)
-                                vp[u] = p + s_vd[sgi];
-                            else
-                                vp[u] = p;
-                            ct[u] = __uint_as_float(rec.y);
+                            vp[u] = sg.vpos + off;
+                            ct[u] = sg.cterm;
                         }
                     }
                 }
@@ -794,12 +783,8 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
     }();
     if (short_form >= 2 && seg_len_hint > 0 && seg_len_hint <= 48) {
         g_scan_kernel_name = "scan_k1_bitmap_kernel";
-        if (t.shard_world > 1)
-            hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4, true>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts,
-                               t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64);
-        else
-            hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4, false>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts,
-                               t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64);
+        hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table,
+                           segs, lpos, hdr, max_seg, nsplit, k64);
         return hipGetLastError();
     }
     if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
