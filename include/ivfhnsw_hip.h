@@ -105,6 +105,14 @@ int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alpha
 int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
                                  const uint8_t *link_counts, const uint32_t *links, const float *vectors);
 
+/* One query per call is how the reference's drivers search (tests/test_ivfhnsw_sift1b.cpp:193-208).  prepare_latency
+ * builds, once per uploaded quantizer, the "fat" copy of the graph the latency form of the walk reads -- every node
+ * with the float rows of its own neighbours, n * 32 * d * 4 bytes (16 GB at 993 127 centroids, d = 128): a whole
+ * workgroup then walks one query with one memory round trip per expansion.  After it, calls with at most 256 queries
+ * take that form (same results: tests/test_latency_gpu.py).  Needs d = 128 or 96, maxM <= 32, at most 2^20 nodes,
+ * efSearch <= 256; otherwise IVFHNSW_ERR_INVALID and nothing changes.  upload_quantizer discards the copy. */
+int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h);
+
 /* The search-time knobs the drivers set as public members (IndexIVF_HNSW.h:61-62, hnswalg.h:69,
  * IndexIVF_HNSW_Grouping.h:18). */
 typedef struct ivfhnsw_search_params {

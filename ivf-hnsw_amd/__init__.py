@@ -27,6 +27,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
+    "ivfhnsw_gpu_prepare_latency",
 )
 
 
@@ -105,6 +106,7 @@ def lib():
         L.ivfhnsw_gpu_pq_train.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_xty.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
@@ -215,6 +217,10 @@ class GpuIndex:
         n, d = v.shape
         l = _np(links, np.uint32).reshape(n, -1)
         _check(lib().ivfhnsw_gpu_upload_quantizer(self._h, n, d, l.shape[1], enterpoint, _ptr(c), _ptr(l), _ptr(v)))
+
+    def prepare_latency(self):
+        """Build the fat graph of the latency walk (one query per call; see ivfhnsw_gpu_prepare_latency)."""
+        _check(lib().ivfhnsw_gpu_prepare_latency(self._h))
 
     # ---- search --------------------------------------------------------------------------------
     @staticmethod

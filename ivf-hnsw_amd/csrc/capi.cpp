@@ -86,7 +86,7 @@ struct ivfhnsw_gpu {
     DevBuf g_alpha, g_nn, g_sizes, g_inter;
     GroupTables g{};
     bool has_group = false;
-    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms;
+    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms, q_fat;
     GraphTables gr{};
     bool has_graph = false;
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
@@ -342,7 +342,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
@@ -681,6 +681,7 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
         const bool late = late_knob < 0 ? n > 255u * 1008u : late_knob == 1;
         h->gr.links_unique = (unique && late) ? 1 : 0;
     }
+    h->gr.fat = nullptr; // the latency form's copy belongs to the previous graph
     h->gr.qrows = nullptr;
     h->gr.nbrows = nullptr;
     h->gr.nbnorms = nullptr;
@@ -693,6 +694,32 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     if ((rc = build_neighbour_rows(h)))
         return rc;
     h->has_graph = true;
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h)
+{
+    if (h && h->is_view)
+        return fail(IVFHNSW_ERR_STATE, "prepare_latency goes to the handle that holds the tables, not to a view of it");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_graph)
+        return fail(IVFHNSW_ERR_STATE, "prepare_latency needs upload_quantizer");
+    if (h->gr.fat)
+        return IVFHNSW_OK;
+    GraphTables probe = h->gr;
+    probe.fat = reinterpret_cast<const float *>(h); // any non-null value: shape check only
+    if (!coarse_latency_supported(probe, 1))
+        return fail(IVFHNSW_ERR_INVALID, "the latency walk needs d = 128 or 96, maxM <= 32 and at most 2^20 nodes "
+                                         "(have d %d, maxM %d, %u nodes); small batches keep the throughput walk",
+                    h->gr.d, h->gr.maxM, h->gr.n);
+    const size_t bytes = (size_t)h->gr.n * 32 * h->gr.d * sizeof(float);
+    if ((rc = h->q_fat.ensure(bytes)))
+        return rc;
+    HIP_TRY(launch_build_fat(h->stream, h->gr, h->q_fat.as<float>()));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->gr.fat = h->q_fat.as<float>();
     return IVFHNSW_OK;
 }
 
@@ -722,6 +749,16 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         return !(e && atoi(e) == 4);
     }();
     StageScope sc(h, IVFHNSW_STAGE_COARSE);
+    // few queries (the reference's drivers: one per call): a workgroup per query on the fat graph, when it was prepared
+    static const size_t lat_max_nq = [] {
+        const char *e = getenv("IVFHNSW_LATENCY_MAX_NQ");
+        return (e && *e) ? (size_t)atol(e) : (size_t)256;
+    }();
+    if (nq <= lat_max_nq && coarse_latency_supported(h->gr, (int)efSearch)) {
+        HIP_TRY(launch_coarse_latency(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
+                                      d_coarse_dists, h->w_status.as<uint32_t>()));
+        return IVFHNSW_OK;
+    }
     if (efSearch <= 256 && !one_per_wave) {
         // four queries per wavefront (kernels_hnsw4.hip)
         const int nwaves = (int)std::min<size_t>((nq + 3) / 4, (size_t)coarse4_waves_resident());
@@ -1414,7 +1451,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

@@ -7,24 +7,30 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge
 import synth
 pkg = ge.load_pkg()
-nc = 1 << 17
-tb = synth.make_throughput_tables(7, nc, 128, 16, 100_000_000)
+big = len(sys.argv) > 1 and sys.argv[1] == "1B"
+nc = 993127 if big else 1 << 17
+tb = synth.make_throughput_tables(7, nc, 128, 16, 1_000_000_000 if big else 100_000_000)
 counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32)
 cn = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
 g = pkg.GpuIndex(0)
 g.upload_ivf_synthetic(128, 16, tb["offsets"], cn, tb["pq_centroids"], tb["norm_table"], 11)
 g.upload_quantizer(counts, links, tb["centroids"], 0)
 rng = np.random.default_rng(1)
-q = (tb["centroids"][rng.choice(nc, 400)] + rng.normal(0, 12, (400, 128))).astype(np.float32)
-for nq in (1, 4, 16, 64, 256):
-    for i in range(0, 40 * nq, nq):
-        g.search(q[i % 300:i % 300 + nq], 1, 32, 10000, efSearch=80)
-    g.set_profiling(True); g.reset_stage_ms()
-    n = 100
-    t0 = time.perf_counter()
-    for i in range(n):
-        g.search(q[(i * nq) % 100:(i * nq) % 100 + nq], 1, 32, 10000, efSearch=80)
-    el = (time.perf_counter() - t0) / n
-    st = g.stage_ms(); g.set_profiling(False)
-    print("nq %4d: %.0f us per call; stages (us per call): %s" % (
-        nq, el * 1e6, {k: round(v[0] / max(1, v[1]) * 1e3, 1) for k, v in st.items()}))
+q = (tb["centroids"][rng.choice(nc, 1400)] + rng.normal(0, 12, (1400, 128))).astype(np.float32)
+def probe(label):
+  for nq in (1, 4, 16, 64, 256, 1024):
+      for i in range(0, 40 * nq, nq):
+          g.search(q[i % 300:i % 300 + nq], 1, 32, 10000, efSearch=80)
+      g.set_profiling(True); g.reset_stage_ms()
+      n = 100
+      t0 = time.perf_counter()
+      for i in range(n):
+          g.search(q[(i * nq) % 100:(i * nq) % 100 + nq], 1, 32, 10000, efSearch=80)
+      el = (time.perf_counter() - t0) / n
+      st = g.stage_ms(); g.set_profiling(False)
+      print(label + " nq %4d: %.0f us per call; stages (us per call): %s" % (
+          nq, el * 1e6, {k: round(v[0] / max(1, v[1]) * 1e3, 1) for k, v in st.items()}))
+
+probe("[throughput walk]")
+g.prepare_latency()
+probe("[latency walk]   ")
