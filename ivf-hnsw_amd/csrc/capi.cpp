@@ -65,6 +65,33 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Pinned, device-visible host memory that only ever grows (the small-batch entry point reads queries and writes
+// results through it: no staging copies on the latency path).
+struct HostBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes)
+            return IVFHNSW_OK;
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        HIP_TRY(hipHostMalloc(&p, need ? need : 1, hipHostMallocDefault));
+        bytes = need;
+        return IVFHNSW_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct StageEvent {
     int stage;
     hipEvent_t a, b;
@@ -101,6 +128,7 @@ struct ivfhnsw_gpu {
         w_slen, w_counter;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
+    HostBuf p_in, p_out; // pinned: small batches
 
     int last_nq = 0, last_max_seg = 0;
     const char *last_scan_kernel = "";
@@ -347,6 +375,8 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
+    h->p_in.release();
+    h->p_out.release();
     if (h->own_stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1357,6 +1387,38 @@ int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries
     if ((coarse_ids == nullptr) != (coarse_dists == nullptr))
         return fail(IVFHNSW_ERR_INVALID, "coarse_ids and coarse_dists must both be given or both be NULL");
     const size_t d = h->t.d;
+    // Small batches -- the reference's drivers pass ONE query per call (tests/test_ivfhnsw_sift1b.cpp:193-208) -- go
+    // through pinned host memory the kernels read and write directly: no staging copies, one synchronisation.  Layout
+    // of the two blocks: in = queries | coarse ids | coarse dists; out = distances | labels | status word.
+    static const size_t pinned_max_nq = [] {
+        const char *e = getenv("IVFHNSW_PINNED_MAX_NQ");
+        return (e && *e) ? (size_t)atol(e) : (size_t)256;
+    }();
+    if (nq <= pinned_max_nq) {
+        const size_t np = p->nprobe;
+        const size_t in_q = nq * d * sizeof(float), in_c = coarse_ids ? nq * np * sizeof(uint32_t) : 0;
+        const size_t out_d = (nq * k * sizeof(float) + 7) & ~(size_t)7, out_l = nq * k * sizeof(int64_t);
+        if ((rc = h->p_in.ensure(in_q + 2 * in_c)) || (rc = h->p_out.ensure(out_d + out_l + 8)))
+            return rc;
+        char *pin = h->p_in.as<char>(), *pout = h->p_out.as<char>();
+        memcpy(pin, queries, in_q);
+        if (coarse_ids) {
+            memcpy(pin + in_q, coarse_ids, in_c);
+            memcpy(pin + in_q + in_c, coarse_dists, in_c);
+        }
+        uint32_t *pst = reinterpret_cast<uint32_t *>(pout + out_d + out_l);
+        rc = ivfhnsw_gpu_search_dev(h, nq, k, reinterpret_cast<const float *>(pin),
+                                    coarse_ids ? reinterpret_cast<const uint32_t *>(pin + in_q) : nullptr,
+                                    coarse_ids ? reinterpret_cast<const float *>(pin + in_q + in_c) : nullptr, p,
+                                    reinterpret_cast<float *>(pout), reinterpret_cast<int64_t *>(pout + out_d), nullptr);
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(pst, h->w_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(distances, pout, nq * k * sizeof(float));
+        memcpy(labels, pout + out_d, out_l);
+        return *pst ? check_status(h) : IVFHNSW_OK;
+    }
     if ((rc = h->s_q.ensure(nq * d * sizeof(float))))
         return rc;
     if ((rc = h->s_dist.ensure(nq * k * sizeof(float))))
