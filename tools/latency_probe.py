@@ -31,6 +31,34 @@ def probe(label):
       print(label + " nq %4d: %.0f us per call; stages (us per call): %s" % (
           nq, el * 1e6, {k: round(v[0] / max(1, v[1]) * 1e3, 1) for k, v in st.items()}))
 
+# the serial CPU port on the same corpus and queries, one query per call as the reference's drivers loop
+# (tests/test_ivfhnsw_sift1b.cpp:193-208); only the lists these queries probe are materialised on the host
+from oracle import orc
+graph = orc.Hnsw.from_arrays(counts, links, tb["centroids"], 16, 0)
+arrays = synth.synthetic_codes_sparse(11, tb["offsets"], 16)
+ox = orc.Index(128, 16, graph, tb["pq_centroids"], tb["norm_table"], tb["offsets"], arrays[0], arrays[1], arrays[2], cn)
+ox.set_params(32, 10000, 80)
+nqc = 400
+_, _, cid, _, _ = ox.search_batch(q[:nqc], 1, 1)
+synth.synthetic_codes_sparse(11, tb["offsets"], 16, cid.ravel()[cid.ravel() < nc], into=arrays)
+ox.search_batch(q[:nqc], 1, 1)
+t0 = time.perf_counter()
+ref_d, ref_l, _, _, _ = ox.search_batch(q[:nqc], 1, 1)
+cpu_us = (time.perf_counter() - t0) / nqc * 1e6
+print("[cpu port, serial] %.0f us per query (%d queries, one thread)" % (cpu_us, nqc))
+
+def check(label):
+    ok = True
+    t0 = time.perf_counter()
+    for i in range(nqc):
+        d1, l1 = g.search(q[i], 1, 32, 10000, efSearch=80)
+        ok &= l1[0, 0] == ref_l[i, 0] and d1.view(np.uint32)[0, 0] == ref_d.view(np.uint32)[i, 0]
+    us = (time.perf_counter() - t0) / nqc * 1e6
+    print("%s one query per call, stage events off: %.0f us per call (cpu port %.0f); results equal to the port: %s"
+          % (label, us, cpu_us, ok))
+
 probe("[throughput walk]")
+check("[throughput walk]")
 g.prepare_latency()
 probe("[latency walk]   ")
+check("[latency walk]   ")
