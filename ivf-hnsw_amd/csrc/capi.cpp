@@ -744,8 +744,7 @@ int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h)
         return fail(IVFHNSW_ERR_INVALID, "the latency walk needs d = 128 or 96, maxM <= 32 and at most 2^20 nodes "
                                          "(have d %d, maxM %d, %u nodes); small batches keep the throughput walk",
                     h->gr.d, h->gr.maxM, h->gr.n);
-    const size_t bytes = (size_t)h->gr.n * 32 * h->gr.d * sizeof(float);
-    if ((rc = h->q_fat.ensure(bytes)))
+    if ((rc = h->q_fat.ensure(coarse_latency_fat_bytes(h->gr))))
         return rc;
     HIP_TRY(launch_build_fat(h->stream, h->gr, h->q_fat.as<float>()));
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -78,7 +78,8 @@ struct GraphTables {
     const uint32_t *nbnorms; // [n][nb_rows] sum of bytes^2 of every neighbour row (the filter's ||c||^2 term)
     int nb_rows;
     // Latency form of the walk (kernels_hnsw_lat.hip): node i carries the FLOAT rows of its own neighbours,
-    // [n][32][d], zero beyond the link count; NULL until ivfhnsw_gpu_prepare_latency builds it.
+    // per node 32 rows of d floats (zero beyond the link count) and a 256-byte trailer with its links and link count;
+    // NULL until ivfhnsw_gpu_prepare_latency builds it.
     const float *fat;
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
     int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
@@ -127,6 +128,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
 int coarse_slots_for(int ef);
 // one workgroup per query on the fat graph (small batches: the reference's one-query-per-call drivers)
 bool coarse_latency_supported(const GraphTables &g, int ef);
+size_t coarse_latency_fat_bytes(const GraphTables &g);
 hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat);
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                                  uint32_t *coarse_ids, float *coarse_dists, uint32_t *status);

@@ -23,24 +23,18 @@
 #include "walk_set.h"
 
 #include <float.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ivfhnsw_gpu_impl {
 
 namespace {
 
-constexpr int LAT_THREADS = 320; // wave 0 + four loader waves
+constexpr int LAT_THREADS = 384; // wave 0, loader waves 1, 2, 3 and 5; wave 4 would share wave 0's SIMD: it leaves
 constexpr uint32_t LAT_CMD_NONE = 0xffffffffu, LAT_CMD_EXIT = 0xfffffffeu;
-
-__device__ __forceinline__ unsigned long long wave_min_u64_l(unsigned long long v)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
+// a fat record: 32 rows of d floats, then a 256-byte trailer -- the node's link list (32 words), its link count, padding --
+// so that ONE touched region carries everything an expansion reads
+constexpr int LAT_TRAILER = 64; // floats
 
 struct LatShared {
     float dist[2][32];     // distances of the node being fetched, double buffered
@@ -48,11 +42,28 @@ struct LatShared {
     uint32_t cnt[2];       // its link count
     uint32_t cmd;          // node the loaders fetch next (LAT_CMD_NONE: nothing, LAT_CMD_EXIT: done)
     uint32_t buf;          // buffer they fill
+    uint32_t touch[2];     // the two candidates after it: their rows are only touched (pulled into L2 and the TLBs)
     unsigned long long tail[kTailCap];
 };
 
 // NJ = d / 8 (16: d = 128, 12: d = 96); NCH = registers of the result set (ef <= 64 * NCH)
-template <int NCH, int NJ>
+__device__ __forceinline__ unsigned long long lat_stamp()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define LAT_STAMP(i)                          \
+    if (STAMPS) {                             \
+        const unsigned long long t_ = lat_stamp(); \
+        st_acc[i] += t_ - st_t;               \
+        st_t = t_;                            \
+    }
+
+// STAMPS: diagnostic instantiation (IVFHNSW_LAT_STAMPS=1), never timed: per-phase s_memtime sums printed per query
+template <int NCH, int NJ, bool STAMPS>
 __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables g, const float *__restrict__ xq, int nq,
                                                                     int nprobe, int ef, uint32_t *__restrict__ coarse_ids,
                                                                     float *__restrict__ coarse_dists,
@@ -79,32 +90,109 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
     if (tid == 0) {
         sh->cmd = LAT_CMD_NONE;
         sh->buf = 0;
+        sh->touch[0] = sh->touch[1] = LAT_CMD_NONE;
     }
     __syncthreads();
 
+    if (wave == 4)
+        return; // waves go to SIMD (wave % 4): nothing shares the SIMD of the serial wave (stamps: its partner delayed
+                // both -- 1300 cycles of wave 0 waiting at B2 per expansion)
     if (wave != 0) {
         // ---- loaders: B1 -> read the command -> fetch -> B2
-        const int r = 8 * (wave - 1) + (lane >> 3); // the row this group of eight lanes evaluates
+        // A fetch from HBM through cold TLBs costs ~5000 cycles here (stamps: wave 0 waited 2300 cycles at B2 AFTER
+        // 2600 cycles of insertions), an L2 hit a few hundred.  So besides the predicted node's rows every round
+        // TOUCHES the rows of the two candidates behind it -- one dword per 128-byte line, 256 lines, one per loader
+        // lane -- which are the nodes most likely to be expanded a round or two later.
+        const int li = wave == 5 ? 3 : wave - 1;    // loader index 0..3
+        const int r = 8 * li + (lane >> 3);         // the row this group of eight lanes evaluates
+        const int tix = li * 64 + lane;             // 0..255: touched node tix >> 7, line tix & 127 of its 16 KB
+        float sink = 0.f;
+        unsigned long long ld_acc[4] = {0, 0, 0, 0}, ld_t = 0;
+        int ld_n = 0;
         for (;;) {
             __syncthreads(); // B1
+            if (STAMPS)
+                ld_t = lat_stamp();
             const uint32_t node = sh->cmd;
             const uint32_t b = sh->buf;
+            const uint32_t tnode = sh->touch[tix >> 7];
             if (node == LAT_CMD_EXIT)
                 break;
+            float tv = 0.f;
             if (node != LAT_CMD_NONE) {
-                const float *row = g.fat + ((size_t)node * 32 + r) * D;
-                const float dq = l2_ref_order_oct_regs<NJ>(row, q_reg, lane & 7);
+                const float *rec = g.fat + (size_t)node * (32 * D + LAT_TRAILER);
+                const float *r1 = rec + r * D + (lane & 7);
+                float y[NJ];
+#pragma unroll
+                for (int i = 0; i < NJ; i++)
+                    y[i] = r1[8 * i];
+                uint32_t lk = 0, ct = 0;
+                if (wave == 1 && lane <= 32)
+                    lk = reinterpret_cast<const uint32_t *>(rec + 32 * D)[lane]; // words 0..31 links, word 32 the count
+                ct = lk;
+                if (tnode < g.n) { // issued behind the rows: the load counter is in order, the rows do not wait for it
+                    const float *trec = g.fat + (size_t)tnode * (32 * D + LAT_TRAILER);
+                    tv = trec[(size_t)(tix & 127) * (D * 32 / 128)];
+                    if ((tix & 127) < 2)
+                        tv += trec[32 * D + 32 * (tix & 127)]; // the trailer's two lines
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (STAMPS) {
+                    unsigned long long t_ = lat_stamp();
+                    ld_acc[0] += t_ - ld_t; // command read, addresses, loads issued
+                    ld_t = t_;
+                    asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // the rows (the touch is the youngest load)
+                    t_ = lat_stamp();
+                    ld_acc[1] += t_ - ld_t; // rows arrived
+                    ld_t = t_;
+                    ld_n++;
+                }
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < NJ; i++) {
+                    const float d0 = __fsub_rn(q_reg[i], y[i]);
+                    acc = __fadd_rn(acc, __fmul_rn(d0, d0));
+                }
+                const float mir = __uint_as_float(
+                    (uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(acc), 0x141, 0xf, 0xf, true));
+                float dq = __fadd_rn(quad_bcast<0>(acc), quad_bcast<1>(acc));
+                dq = __fadd_rn(dq, quad_bcast<2>(acc));
+                dq = __fadd_rn(dq, quad_bcast<3>(acc));
+                dq = __fadd_rn(dq, quad_bcast<3>(mir));
+                dq = __fadd_rn(dq, quad_bcast<2>(mir));
+                dq = __fadd_rn(dq, quad_bcast<1>(mir));
+                dq = __fadd_rn(dq, quad_bcast<0>(mir));
                 if ((lane & 7) == 0)
                     sh->dist[b][r] = dq;
                 if (wave == 1) {
                     if (lane < 32)
-                        sh->link[b][lane] = lane < g.maxM ? g.links[(size_t)node * g.maxM + lane] : 0u;
+                        sh->link[b][lane] = lk;
                     if (lane == 32)
-                        sh->cnt[b] = g.counts[node];
+                        sh->cnt[b] = ct;
                 }
             }
-            __syncthreads(); // B2
+            if (STAMPS) {
+                const unsigned long long t_ = lat_stamp();
+                ld_acc[2] += t_ - ld_t; // arithmetic, reduction, LDS writes
+                ld_t = t_;
+            }
+            // B2 by hand: __syncthreads() drains vmcnt before its s_barrier, i.e. it would make every loader wait for its
+            // TOUCH load (a whole HBM round trip nobody needs yet: 1300 cycles of wave 0 standing at B2 per expansion,
+            // stamps).  What wave 0 reads after B2 are the LDS writes above: lgkmcnt(0) is all the barrier has to cover.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("" : "+v"(tv)); // the touch is waited for here, off the critical path
+            sink += tv;
+            if (STAMPS) {
+                const unsigned long long t_ = lat_stamp();
+                ld_acc[3] += t_ - ld_t; // B2 and the touch
+            }
         }
+        if (STAMPS && (tid == 64 || tid == 320) && ld_n)
+            printf("[lat stamps] loaders, %d fetches; cycles/fetch: issue %llu, rows arrive %llu, arithmetic %llu, B2 + touch %llu\n",
+                   ld_n, ld_acc[0] / ld_n, ld_acc[1] / ld_n, ld_acc[2] / ld_n, ld_acc[3] / ld_n);
+        if (sink == 1.2345678e30f) // never: keeps the touches alive
+            status[1] = 0u;
         return;
     }
 
@@ -127,8 +215,15 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
     uint32_t have_node = LAT_CMD_NONE; // node whose rows the loaders have fetched (into buffer cur)
     uint32_t cur = 0;
     bool overflow = false;
+    bool preselected = false; // the end of the previous expansion already popped the next node (fast path below)
+    uint32_t node = 0;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = STAMPS ? lat_stamp() : 0ull;
+    int st_exp = 0, st_miss = 0, st_fast = 0, st_adm = 0;
 
     for (;;) {
+      if (STAMPS)
+          st_fast += preselected ? 1 : 0;
+      if (!preselected) {
         // ---- candidateSet.top(): first unexpanded entry of R, ties -> largest id; tail joins at dist == max
         const int first = R.first_unexpanded(n, lane);
         int pick = -1, pick_tail = -1;
@@ -172,7 +267,14 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        const uint32_t node = pick_id;
+        node = pick_id;
+      }
+        preselected = false;
+        LAT_STAMP(0) // selection
+        if (STAMPS) {
+            st_exp++;
+            st_miss += have_node != node ? 1 : 0;
+        }
 
         // ---- the node's rows: already fetched if the prediction held, else one more round
         if (have_node != node) {
@@ -184,6 +286,7 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
             __syncthreads(); // B1
             __syncthreads(); // B2
         }
+        LAT_STAMP(1) // waiting for a node that was not predicted
         const int cnt = (int)sh->cnt[cur];
         const uint32_t nb = lane < 32 ? sh->link[cur][lane] : 0u;
         const float dq = lane < 32 ? sh->dist[cur][lane] : 0.f;
@@ -199,23 +302,71 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
         const float top0 = __uint_as_float(key_dist_bits(topk));
         unsigned long long cand = __ballot(fresh && (n < ef || top0 > dq));
 
+        LAT_STAMP(2) // staged rows, visited test, candidate mask
         // ---- prediction of the node after this one: the nearer of R's next unexpanded entry and the best new candidate
+        unsigned long long pred_key = ~0ull;
         {
-            const unsigned long long kc = ((cand >> lane) & 1ull) ? mk_key(dq, nb) : ~0ull;
-            const unsigned long long best_new = wave_min_u64_l(kc);
-            const int f2 = R.first_unexpanded(n, lane);
+            // (a handful of candidates: their minimum on the scalar unit, two v_readlane each -- a wave-wide 64-bit
+            // minimum is six dependent cross-lane round trips, which a lone wavefront waits out one by one)
+            unsigned long long best_new = ~0ull;
+            for (unsigned long long cm = cand; cm; cm &= cm - 1) {
+                const int b = __ffsll((long long)cm) - 1;
+                const uint32_t dbj = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b);
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nb, b);
+                const unsigned long long kj = ((unsigned long long)dbj << 32) | ((unsigned long long)idj << 1);
+                best_new = kj < best_new ? kj : best_new;
+            }
+            // R's unexpanded entries: the first is the old candidate of the prediction, the next two are what the
+            // loaders touch (from the same ballots: scalar bit picking and two v_readlane each)
+            int f2 = -1;
+            uint32_t t0 = LAT_CMD_NONE, t1 = LAT_CMD_NONE;
+            {
+                int seen = 0;
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    unsigned long long m = __ballot(!(R.r[cc] & 1ull)) & lanes_below(n, cc);
+                    if (m && seen < 3) {
+                        const int l0 = __ffsll((long long)m) - 1;
+                        if (seen == 0)
+                            f2 = cc * 64 + l0;
+                        else if (seen == 1)
+                            t0 = key_id(readlane_u64(R.r[cc], l0));
+                        else
+                            t1 = key_id(readlane_u64(R.r[cc], l0));
+                        seen++;
+                        m &= m - 1;
+                        if (m && seen < 3) {
+                            const int l1 = __ffsll((long long)m) - 1;
+                            if (seen == 1)
+                                t0 = key_id(readlane_u64(R.r[cc], l1));
+                            else
+                                t1 = key_id(readlane_u64(R.r[cc], l1));
+                            seen++;
+                            m &= m - 1;
+                            if (m && seen < 3) {
+                                t1 = key_id(readlane_u64(R.r[cc], __ffsll((long long)m) - 1));
+                                seen++;
+                            }
+                        }
+                    }
+                }
+            }
             const unsigned long long best_old = f2 >= 0 ? (R.get(f2) & ~1ull) : ~0ull;
             const unsigned long long best = best_new < best_old ? best_new : best_old;
+            pred_key = best;
             const uint32_t pred = best == ~0ull ? LAT_CMD_NONE : key_id(best);
             cur ^= 1u;
             if (lane == 0) {
                 sh->cmd = pred;
                 sh->buf = cur;
+                sh->touch[0] = t0;
+                sh->touch[1] = t1;
             }
             have_node = pred;
             __syncthreads(); // B1: the loaders start on the predicted node
         }
 
+        LAT_STAMP(3) // prediction + B1
         // ---- admissions in link order (hnswalg.cpp:93-103)
         while (cand) {
             const int b = __ffsll((long long)cand) - 1;
@@ -227,6 +378,8 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
                 continue;
             const unsigned long long K = mk_key(dj, idj);
             const bool full = n == ef;
+            if (STAMPS)
+                st_adm++;
             R.insert_sorted(K, lane);
             if (!full)
                 n++;
@@ -251,10 +404,41 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
                 }
             }
         }
+        LAT_STAMP(4) // admissions
         __syncthreads(); // B2: the predicted node's rows are in buffer cur
+        LAT_STAMP(5) // waiting for the loaders at B2
         if (overflow)
             break;
+        // ---- fast pop: the predicted key is the smallest of all unexpanded entries and all candidates of this
+        // expansion, so after the insertions it IS the first unexpanded entry -- unless it was not admitted or evicted
+        // (then it is absent) or another unexpanded entry shares its distance (the reference pops the LARGEST id of
+        // equal distances: the full selection decides).  One compare per register instead of the search above.
+        if (ntail == 0 && pred_key != ~0ull) {
+            const uint32_t pd = key_dist_bits(pred_key);
+            int found = 0, same = 0;
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++) {
+                const bool live = !(R.r[cc] & 1ull);
+                const unsigned long long in = lanes_below(n, cc);
+                found += __popcll(__ballot(live && (R.r[cc] & ~1ull) == pred_key) & in);
+                same += __popcll(__ballot(live && key_dist_bits(R.r[cc]) == pd) & in);
+            }
+            if (found == 1 && same == 1) {
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++)
+                    if ((R.r[cc] & ~1ull) == pred_key && cc * 64 + lane < n)
+                        R.r[cc] |= 1ull;
+                node = key_id(pred_key);
+                preselected = true;
+            }
+        }
+        LAT_STAMP(6) // fast pop
     }
+    if (STAMPS && lane == 0)
+        printf("[lat stamps] query %d: %d expansions (%d not predicted, %d fast pops, %d admissions); cycles/expansion: "
+               "select %llu, unpredicted wait %llu, stage+visited %llu, predict+B1 %llu, admissions %llu, B2 wait %llu, "
+               "fast pop %llu\n", q, st_exp, st_miss, st_fast, st_adm, st_acc[0] / st_exp, st_acc[1] / st_exp,
+               st_acc[2] / st_exp, st_acc[3] / st_exp, st_acc[4] / st_exp, st_acc[5] / st_exp, st_acc[6] / st_exp);
     if (lane == 0)
         sh->cmd = LAT_CMD_EXIT;
     __syncthreads(); // B1 of the loaders' last round
@@ -271,13 +455,22 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
     }
 }
 
-// fat[i][r][:] = vectors[links[i][r]] for r < counts[i], zero beyond: one workgroup per node
+// fat[i]: rows r < counts[i] = vectors[links[i][r]], zero beyond; then the trailer.  One workgroup per node.
 __global__ __launch_bounds__(256) void build_fat_kernel(GraphTables g, float *__restrict__ fat)
 {
     const size_t node = blockIdx.x;
     const int cnt = g.counts[node];
     const int d4 = g.d >> 2;
-    float4 *dst = reinterpret_cast<float4 *>(fat + node * 32 * (size_t)g.d);
+    float *rec = fat + node * (32 * (size_t)g.d + LAT_TRAILER);
+    if (threadIdx.x < LAT_TRAILER) {
+        uint32_t w = 0;
+        if ((int)threadIdx.x < cnt)
+            w = g.links[node * g.maxM + threadIdx.x];
+        else if (threadIdx.x == 32)
+            w = (uint32_t)cnt;
+        reinterpret_cast<uint32_t *>(rec + 32 * (size_t)g.d)[threadIdx.x] = w;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(rec);
     for (int e = threadIdx.x; e < 32 * d4; e += 256) {
         const int r = e / d4, c = e - r * d4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -293,6 +486,8 @@ bool coarse_latency_supported(const GraphTables &g, int ef)
 {
     return g.fat && (g.d == 128 || g.d == 96) && g.maxM <= 32 && g.n <= (1u << 20) && ef <= 256;
 }
+
+size_t coarse_latency_fat_bytes(const GraphTables &g) { return (size_t)g.n * (32 * (size_t)g.d + LAT_TRAILER) * sizeof(float); }
 
 hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat)
 {
@@ -311,9 +506,13 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
         return hipErrorInvalidValue;
     const size_t shm = ((sizeof(LatShared) + 15) & ~(size_t)15) + (size_t)((g.n + 127u) / 128u) * 16;
     const int nch = (ef + 63) / 64;
+    static const bool stamps = [] {
+        const char *e = getenv("IVFHNSW_LAT_STAMPS");
+        return e && atoi(e) == 1;
+    }();
 #define IVFHNSW_LAT(N, J)                                                                                             \
     do {                                                                                                              \
-        auto *kern = hnsw_walk_lat_kernel<N, J>;                                                                      \
+        auto *kern = stamps ? hnsw_walk_lat_kernel<N, J, true> : hnsw_walk_lat_kernel<N, J, false>;                   \
         static size_t attr = 0;                                                                                       \
         if (shm > attr) {                                                                                             \
             hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
