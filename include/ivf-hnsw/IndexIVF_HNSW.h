@@ -127,6 +127,10 @@ protected:
     void upload_graph();
     bool graph_dirty_;
     const void *graph_uploaded_for_;
+    /// one query per call (what search() is): the latency form of the coarse walk, prepared at the first such call
+    /// (ivfhnsw_gpu_prepare_latency; IVFHNSW_LATENCY=0 keeps the throughput walk)
+    void ensure_latency_walk();
+    const void *latency_for_;
 
 private:
     void reconstruct(size_t n, float *x, const float *decoded_residuals, const idx_t *keys);

@@ -80,6 +80,8 @@ void IndexIVF_HNSW_Grouping::search(size_t k, const float *x, float *distances, 
     trace_query_centroid_dists.clear();
     trace_centroid_idxs.clear();
 #endif
+    ensure_device();
+    ensure_latency_walk();
     search_batch(1, k, x, distances, labels);
 }
 

@@ -7,6 +7,7 @@
 
 #include <ivfhnsw_hip.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -25,7 +26,7 @@ namespace {
 IndexIVF_HNSW::IndexIVF_HNSW(size_t dim, size_t ncentroids, size_t bytes_per_code, size_t nbits_per_idx,
                              size_t max_group_size)
     : d(dim), nc(ncentroids), code_size(0), quantizer(nullptr), pq(nullptr), norm_pq(nullptr), opq_matrix(nullptr),
-      do_opq(false), nprobe(1), max_codes(0), M(16), gpu_(nullptr), device_dirty_(true), graph_dirty_(true), graph_uploaded_for_(nullptr), up_pq_(nullptr),
+      do_opq(false), nprobe(1), max_codes(0), M(16), gpu_(nullptr), device_dirty_(true), graph_dirty_(true), graph_uploaded_for_(nullptr), latency_for_(nullptr), up_pq_(nullptr),
       up_norm_pq_(nullptr), up_opq_(nullptr), up_quantizer_(nullptr), up_total_(0), up_do_opq_(false)
 {
     std::memset(&hdr_idx, 0, sizeof(hdr_idx));
@@ -77,11 +78,32 @@ void IndexIVF_HNSW::build_quantizer(const char *path_data, const char *path_info
 }
 
 // ------------------------------------------------------------------------------------------ device mirror
+void IndexIVF_HNSW::ensure_latency_walk()
+{
+    // once per uploaded graph; shapes the latency form does not take (IVFHNSW_ERR_INVALID) keep the throughput walk
+    static const bool off = [] {
+        const char *e = getenv("IVFHNSW_LATENCY");
+        return e && *e && atoi(e) == 0;
+    }();
+    if (off || latency_for_ == graph_uploaded_for_ || !graph_uploaded_for_)
+        return;
+    latency_for_ = graph_uploaded_for_;
+    const int rc = ivfhnsw_gpu_prepare_latency(gpu_);
+    if (rc != IVFHNSW_OK && rc != IVFHNSW_ERR_INVALID)
+        gpu_fail("ivfhnsw_gpu_prepare_latency");
+}
+
 void IndexIVF_HNSW::ensure_device()
 {
-    size_t total = 0;
-    for (size_t c = 0; c < nc; c++)
-        total += ids[c].size();
+    // The list total is the fingerprint that catches a driver appending to the public lists behind the class's back;
+    // summing a million list sizes per call would cost more than the search itself (one query per call at 993 127
+    // centroids), so beyond 2^16 lists the class relies on its own dirty flags (add_batch, read, invalidate_device()).
+    size_t total = up_total_;
+    if (nc <= (1u << 16) || !gpu_) {
+        total = 0;
+        for (size_t c = 0; c < nc; c++)
+            total += ids[c].size();
+    }
     if (!gpu_ || device_dirty_ || up_pq_ != pq || up_norm_pq_ != norm_pq || up_opq_ != opq_matrix ||
         up_quantizer_ != quantizer || up_total_ != total || up_do_opq_ != do_opq)
         sync_to_device();
@@ -215,6 +237,8 @@ void IndexIVF_HNSW::search(size_t k, const float *x, float *distances, long *lab
     trace_query_centroid_dists.clear();
     trace_centroid_idxs.clear();
 #endif
+    ensure_device();
+    ensure_latency_walk();
     search_batch(1, k, x, distances, labels);
 }
 

@@ -67,8 +67,10 @@ template <int NCH, int NJ, bool STAMPS>
 __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables g, const float *__restrict__ xq, int nq,
                                                                     int nprobe, int ef, uint32_t *__restrict__ coarse_ids,
                                                                     float *__restrict__ coarse_dists,
-                                                                    uint32_t *__restrict__ status)
+                                                                    uint32_t *__restrict__ status, int diag)
 {
+    // diag (STAMPS builds only, IVFHNSW_LAT_DIAG=1): the loaders skip their fetch -- results are garbage, what is read
+    // off the stamps is the cost of the two barriers alone
     constexpr int D = NJ * 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_lat[];
     LatShared *sh = reinterpret_cast<LatShared *>(smem_lat);
@@ -118,31 +120,33 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
             const uint32_t tnode = sh->touch[tix >> 7];
             if (node == LAT_CMD_EXIT)
                 break;
-            float tv = 0.f;
-            if (node != LAT_CMD_NONE) {
+            float tv_a = 0.f, tv_b = 0.f;
+            if (node != LAT_CMD_NONE && !(STAMPS && diag)) {
                 const float *rec = g.fat + (size_t)node * (32 * D + LAT_TRAILER);
                 const float *r1 = rec + r * D + (lane & 7);
                 float y[NJ];
 #pragma unroll
                 for (int i = 0; i < NJ; i++)
                     y[i] = r1[8 * i];
-                uint32_t lk = 0, ct = 0;
-                if (wave == 1 && lane <= 32)
-                    lk = reinterpret_cast<const uint32_t *>(rec + 32 * D)[lane]; // words 0..31 links, word 32 the count
-                ct = lk;
-                if (tnode < g.n) { // issued behind the rows: the load counter is in order, the rows do not wait for it
-                    const float *trec = g.fat + (size_t)tnode * (32 * D + LAT_TRAILER);
-                    tv = trec[(size_t)(tix & 127) * (D * 32 / 128)];
-                    if ((tix & 127) < 2)
-                        tv += trec[32 * D + 32 * (tix & 127)]; // the trailer's two lines
-                }
+                // Everything below is issued by EVERY lane without a branch in between: with loads under control flow
+                // hipcc counts only the sixteen row loads and waits vmcnt(15..0) for them -- and vmcnt(0) before the
+                // last row means waiting for the touches behind it, a whole HBM round trip on the critical path (stamps:
+                // 1300 cycles of every wave standing at B2).  Unconditional, they are the youngest three loads and the
+                // rows are waited for with vmcnt(18..3).
+                uint32_t lk = reinterpret_cast<const uint32_t *>(rec + 32 * D)[lane < 32 ? lane : 32]; // links | count
+                uint32_t ct = lk;
+                // touches: line tix & 127 of one of the two nodes behind the predicted one, and (cheap: the same line
+                // for most lanes) the trailer's two lines; an absent node re-touches the record being read anyway
+                const float *trec = tnode < g.n ? g.fat + (size_t)tnode * (32 * D + LAT_TRAILER) : rec;
+                const float tv0 = trec[(size_t)(tix & 127) * (D * 32 / 128)];
+                const float tv1 = trec[(tix & 127) < 2 ? 32 * D + 32 * (tix & 127) : (size_t)(tix & 127) * (D * 32 / 128)];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (STAMPS) {
                     unsigned long long t_ = lat_stamp();
                     ld_acc[0] += t_ - ld_t; // command read, addresses, loads issued
                     ld_t = t_;
-                    asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); // the rows (the touch is the youngest load)
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); // rows and trailer (the two touches are the youngest loads)
                     t_ = lat_stamp();
                     ld_acc[1] += t_ - ld_t; // rows arrived
                     ld_t = t_;
@@ -171,6 +175,8 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
                     if (lane == 32)
                         sh->cnt[b] = ct;
                 }
+                tv_a = tv0;
+                tv_b = tv1;
             }
             if (STAMPS) {
                 const unsigned long long t_ = lat_stamp();
@@ -180,16 +186,15 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
             // B2 by hand: __syncthreads() drains vmcnt before its s_barrier, i.e. it would make every loader wait for its
             // TOUCH load (a whole HBM round trip nobody needs yet: 1300 cycles of wave 0 standing at B2 per expansion,
             // stamps).  What wave 0 reads after B2 are the LDS writes above: lgkmcnt(0) is all the barrier has to cover.
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            asm volatile("" : "+v"(tv)); // the touch is waited for here, off the critical path
-            sink += tv;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(sink) : : "memory");
+            sink += tv_a + tv_b; // the touches are waited for here (the asm's output pins the add behind the barrier)
             if (STAMPS) {
                 const unsigned long long t_ = lat_stamp();
                 ld_acc[3] += t_ - ld_t; // B2 and the touch
             }
         }
-        if (STAMPS && (tid == 64 || tid == 320) && ld_n)
-            printf("[lat stamps] loaders, %d fetches; cycles/fetch: issue %llu, rows arrive %llu, arithmetic %llu, B2 + touch %llu\n",
+        if (STAMPS && lane == 0 && ld_n)
+            printf("[lat stamps] loader wave %d, %d fetches; cycles/fetch: issue %llu, rows arrive %llu, arithmetic %llu, B2 + touch %llu\n", wave,
                    ld_n, ld_acc[0] / ld_n, ld_acc[1] / ld_n, ld_acc[2] / ld_n, ld_acc[3] / ld_n);
         if (sink == 1.2345678e30f) // never: keeps the touches alive
             status[1] = 0u;
@@ -510,6 +515,10 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
         const char *e = getenv("IVFHNSW_LAT_STAMPS");
         return e && atoi(e) == 1;
     }();
+    static const int diag = [] {
+        const char *e = getenv("IVFHNSW_LAT_DIAG");
+        return (e && atoi(e) == 1) ? 1 : 0;
+    }();
 #define IVFHNSW_LAT(N, J)                                                                                             \
     do {                                                                                                              \
         auto *kern = stamps ? hnsw_walk_lat_kernel<N, J, true> : hnsw_walk_lat_kernel<N, J, false>;                   \
@@ -521,7 +530,7 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
             attr = shm;                                                                                               \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(nq), dim3(LAT_THREADS), shm, s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, \
-                           status);                                                                                   \
+                           status, diag);                                                                                   \
     } while (0)
 #define IVFHNSW_LAT_J(N)       \
     do {                       \
