@@ -125,13 +125,15 @@ struct ivfhnsw_gpu {
 
     // per-batch workspace
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
-        w_slen, w_counter;
+        w_slen, w_counter, w_tail;
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
     HostBuf p_in, p_out; // pinned: small batches
 
     int last_nq = 0, last_max_seg = 0;
     const char *last_scan_kernel = "";
+    uint32_t *tail_status_out = nullptr; // pinned word the tail kernel copies the status into (host-pointer path)
+    bool tail_wrote_status = false;
     bool last_stream = false; // the last search left a candidate stream (k > 1, heap_order)
 
     bool profiling = false;
@@ -372,7 +374,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
     for (auto *b : all)
         b->release();
     h->p_in.release();
@@ -1239,6 +1241,32 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         cid = h->w_cid.as<uint32_t>();
         cd = h->w_cd.as<float>();
     }
+    // small IVFADC batches: everything behind the coarse stage in one launch (kernels_tail.hip)
+    h->tail_wrote_status = false;
+    {
+        static const size_t tail_max_nq = [] {
+            const char *e = getenv("IVFHNSW_TAIL_MAX_NQ");
+            return (e && *e) ? (size_t)atol(e) : (size_t)256;
+        }();
+        if (!h->has_group && nq <= tail_max_nq && !d_out_keys && ivf_tail_supported(h->t, nprobe, (int)k)) {
+            const size_t kbytes = nq * sizeof(uint64_t);
+            if ((rc = h->w_tail.ensure(kbytes + nq * sizeof(uint32_t))))
+                return rc;
+            const int nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
+            StageScope sc(h, IVFHNSW_STAGE_SCAN);
+            HIP_TRY(hipMemsetAsync(h->w_tail.p, 0, kbytes + nq * sizeof(uint32_t), h->stream));
+            HIP_TRY(launch_ivf_tail(h->stream, h->t, xq, cid, cd, (int)nq, nprobe, p->max_codes, nsplit,
+                                    h->w_tail.as<uint64_t>(), reinterpret_cast<uint32_t *>(h->w_tail.as<char>() + kbytes),
+                                    h->w_hdr.as<PlanHdr>(), d_distances, d_labels, h->w_status.as<uint32_t>(),
+                                    h->tail_status_out));
+            h->tail_wrote_status = h->tail_status_out != nullptr;
+            h->last_scan_kernel = "ivf_tail_kernel";
+            h->last_nq = (int)nq;
+            h->last_max_seg = max_seg;
+            h->last_stream = false;
+            return IVFHNSW_OK;
+        }
+    }
     // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
     {
         StageScope sc(h, IVFHNSW_STAGE_PLAN);
@@ -1406,13 +1434,16 @@ int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries
             memcpy(pin + in_q + in_c, coarse_dists, in_c);
         }
         uint32_t *pst = reinterpret_cast<uint32_t *>(pout + out_d + out_l);
+        h->tail_status_out = pst;
         rc = ivfhnsw_gpu_search_dev(h, nq, k, reinterpret_cast<const float *>(pin),
                                     coarse_ids ? reinterpret_cast<const uint32_t *>(pin + in_q) : nullptr,
                                     coarse_ids ? reinterpret_cast<const float *>(pin + in_q + in_c) : nullptr, p,
                                     reinterpret_cast<float *>(pout), reinterpret_cast<int64_t *>(pout + out_d), nullptr);
+        h->tail_status_out = nullptr;
         if (rc)
             return rc;
-        HIP_TRY(hipMemcpyAsync(pst, h->w_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        if (!h->tail_wrote_status)
+            HIP_TRY(hipMemcpyAsync(pst, h->w_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         memcpy(distances, pout, nq * k * sizeof(float));
         memcpy(labels, pout + out_d, out_l);
@@ -1513,7 +1544,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

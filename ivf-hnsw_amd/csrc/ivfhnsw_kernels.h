@@ -109,6 +109,11 @@ bool scan_fused_supported(const IvfTables &t, bool short_segments);
 hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
                              const PlanHdr *hdr, int max_seg, int nq, int nsplit, uint64_t *keys, uint32_t *counter,
                              bool short_segments); // short_segments: sub-group plans (Grouping), see kernels_scan2.hip
+// plan + table + scan + select of a small IVFADC batch in one launch (kernels_tail.hip); keys_inv [nq] and done [nq] zeroed
+bool ivf_tail_supported(const IvfTables &t, int nprobe, int k);
+hipError_t launch_ivf_tail(hipStream_t s, const IvfTables &t, const float *xq, const uint32_t *cid, const float *cd,
+                           int nq, int nprobe, uint64_t max_codes, int nsplit, uint64_t *keys_inv, uint32_t *done,
+                           PlanHdr *hdr, float *dist, int64_t *labels, const uint32_t *status_word, uint32_t *status_out);
 const char *last_scan_kernel_name(); // the kernel the calling thread's last launch_scan chose
 // k > 1 in faiss heap-array order: sequential replay of the top-k kernel's candidate stream
 hipError_t launch_heap_replay(hipStream_t s, const IvfTables &t, const Seg *segs, const PlanHdr *hdr, int max_seg,

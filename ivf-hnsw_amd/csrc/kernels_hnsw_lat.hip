@@ -44,6 +44,7 @@ struct LatShared {
     uint32_t buf;          // buffer they fill
     uint32_t touch[2];     // the two candidates after it: their rows are only touched (pulled into L2 and the TLBs)
     unsigned long long tail[kTailCap];
+    unsigned long long mb[256 + 32]; // merge buffer: the full set and the candidates of one expansion
 };
 
 // NJ = d / 8 (16: d = 128, 12: d = 96); NCH = registers of the result set (ef <= 64 * NCH)
@@ -123,11 +124,15 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
             float tv_a = 0.f, tv_b = 0.f;
             if (node != LAT_CMD_NONE && !(STAMPS && diag)) {
                 const float *rec = g.fat + (size_t)node * (32 * D + LAT_TRAILER);
-                const float *r1 = rec + r * D + (lane & 7);
+                // a fat row is stored TRANSPOSED for this read: lane t's NJ components (x[8j + t], j = 0..NJ-1: accumulator t
+                // of the reference's eight) are contiguous, NJ / 4 sixteen-byte loads instead of NJ dword loads
+                const float4 *r4 = reinterpret_cast<const float4 *>(rec + r * D + (lane & 7) * NJ);
                 float y[NJ];
 #pragma unroll
-                for (int i = 0; i < NJ; i++)
-                    y[i] = r1[8 * i];
+                for (int i = 0; i < NJ / 4; i++) {
+                    const float4 v = r4[i];
+                    y[4 * i] = v.x, y[4 * i + 1] = v.y, y[4 * i + 2] = v.z, y[4 * i + 3] = v.w;
+                }
                 // Everything below is issued by EVERY lane without a branch in between: with loads under control flow
                 // hipcc counts only the sixteen row loads and waits vmcnt(15..0) for them -- and vmcnt(0) before the
                 // last row means waiting for the touches behind it, a whole HBM round trip on the critical path (stamps:
@@ -372,6 +377,58 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
         }
 
         LAT_STAMP(3) // prediction + B1
+        // ---- all admissions of the expansion in one step (the merge of kernels_hnsw.hip, here over up to 32 candidates).
+        // With the set full, inserting the candidates one by one in link order (below) leaves the ef smallest keys of
+        // set + candidates PROVIDED the ef-th and (ef+1)-th of the merged order differ in distance: every loser then lies
+        // above the final maximum, no strict-'<' tie decided anything, nothing can wait in the tail.  Every candidate is
+        // ranked among the set and the candidates, every set entry among the candidates, the merged order is scattered
+        // through LDS and its boundary inspected; a tie there leaves the registers untouched for the sequential path.
+        if (NCH <= 4 && n == ef && ntail == 0 && cand) {
+            const bool is_cand = (cand >> lane) & 1ull;
+            const unsigned long long Kc = mk_key(dq, nb);
+            int dn[NCH];
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++)
+                dn[cc] = 0;
+            const int ncand = __popcll(cand);
+            int cand_below = 0, set_below = 0;
+            for (unsigned long long cm = cand; cm; cm &= cm - 1) {
+                const int b = __ffsll((long long)cm) - 1;
+                const unsigned long long Kj = readlane_u64(Kc, b);
+                int below = 0;
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    const bool lt = (R.r[cc] & ~1ull) < Kj;
+                    below += __popcll(__ballot(lt) & lanes_below(ef, cc));
+                    dn[cc] += lt ? 1 : 0;
+                }
+                cand_below += Kj < Kc ? 1 : 0;
+                set_below = lane == b ? below : set_below;
+            }
+            unsigned long long *mb = sh->mb;
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++)
+                if (cc * 64 + lane < ef)
+                    mb[cc * 64 + lane + (ncand - dn[cc])] = R.r[cc];
+            if (is_cand)
+                mb[set_below + cand_below] = Kc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long b_lo = mb[ef - 1], b_hi = mb[ef];
+            unsigned long long merged[NCH];
+#pragma unroll
+            for (int cc = 0; cc < NCH; cc++)
+                merged[cc] = cc * 64 + lane < ef ? mb[cc * 64 + lane] : R.r[cc];
+            if (key_dist_bits(b_lo) != key_dist_bits(b_hi)) {
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++)
+                    R.r[cc] = merged[cc];
+                if (STAMPS)
+                    st_adm += ncand;
+                cand = 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         // ---- admissions in link order (hnswalg.cpp:93-103)
         while (cand) {
             const int b = __ffsll((long long)cand) - 1;
@@ -475,13 +532,16 @@ __global__ __launch_bounds__(256) void build_fat_kernel(GraphTables g, float *__
             w = (uint32_t)cnt;
         reinterpret_cast<uint32_t *>(rec + 32 * (size_t)g.d)[threadIdx.x] = w;
     }
-    float4 *dst = reinterpret_cast<float4 *>(rec);
-    for (int e = threadIdx.x; e < 32 * d4; e += 256) {
-        const int r = e / d4, c = e - r * d4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // rows transposed for the loaders: element t * (d / 8) + j of a row is component 8j + t of the neighbour
+    const int nj = g.d >> 3;
+    (void)d4;
+    for (int e = threadIdx.x; e < 32 * g.d; e += 256) {
+        const int r = e / g.d, o = e - r * g.d;
+        const int t = o / nj, j = o - t * nj;
+        float v = 0.f;
         if (r < cnt)
-            v = reinterpret_cast<const float4 *>(g.vectors + (size_t)g.links[node * g.maxM + r] * g.d)[c];
-        dst[e] = v;
+            v = g.vectors[(size_t)g.links[node * g.maxM + r] * g.d + 8 * j + t];
+        rec[e] = v;
     }
 }
 

@@ -64,6 +64,7 @@ def test_every_knob_setting_reproduces_the_default_path():
                 {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "16"}, {"IVFHNSW_WALK_LATE_VISIT": "0"},
                 {"IVFHNSW_SCAN_SHORT": "0"},         # Grouping plans through the position form of the scan
                 {"IVFHNSW_SCAN_SHORT": "1"},         # ... through the lane-group-per-segment form (default: the bitmap form)
+                {"IVFHNSW_TAIL": "0"},               # small batches through the four separate launches
                 {"IVFHNSW_SCAN_FUSED": "1"},         # table + scan fused (kernels_scan2.hip), both segment forms
                 {"IVFHNSW_SCAN_U": "2"}, {"IVFHNSW_SCAN_REP": "2"}):
         assert _run(env) == base, env
