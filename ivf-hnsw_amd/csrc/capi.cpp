@@ -134,6 +134,9 @@ struct ivfhnsw_gpu {
     const char *last_scan_kernel = "";
     uint32_t *tail_status_out = nullptr; // pinned word the tail kernel copies the status into (host-pointer path)
     bool tail_wrote_status = false;
+    uint64_t *walk_zero_keys = nullptr; // the tail kernel's meeting words, cleared by the latency walk when it runs
+    uint32_t *walk_zero_done = nullptr;
+    bool walk_zeroed = false;
     bool last_stream = false; // the last search left a candidate stream (k > 1, heap_order)
 
     bool profiling = false;
@@ -787,7 +790,10 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
     }();
     if (nq <= lat_max_nq && coarse_latency_supported(h->gr, (int)efSearch)) {
         HIP_TRY(launch_coarse_latency(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                                      d_coarse_dists, h->w_status.as<uint32_t>()));
+                                      d_coarse_dists, h->w_status.as<uint32_t>(), h->walk_zero_keys, h->walk_zero_done));
+        h->walk_zeroed = h->walk_zero_keys != nullptr;
+        h->walk_zero_keys = nullptr; // consumed: set by search_dev right before the call, never carried over
+        h->walk_zero_done = nullptr;
         return IVFHNSW_OK;
     }
     if (efSearch <= 256 && !one_per_wave) {
@@ -1227,6 +1233,24 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         HIP_TRY(launch_opq(h->stream, h->t.opq_At, d_queries, h->w_xq.as<float>(), (int)nq, d));
         xq = h->w_xq.as<float>();
     }
+    // small IVFADC batches: everything behind the coarse stage in one launch (kernels_tail.hip); its per-query
+    // meeting words are cleared by the latency walk when that runs, by a memset otherwise
+    static const size_t tail_max_nq = [] {
+        const char *e = getenv("IVFHNSW_TAIL_MAX_NQ");
+        return (e && *e) ? (size_t)atol(e) : (size_t)8;
+    }();
+    const bool use_tail =
+        !h->has_group && nq <= tail_max_nq && !d_out_keys && ivf_tail_supported(h->t, nprobe, (int)k);
+    const size_t tail_kbytes = nq * sizeof(uint64_t);
+    h->walk_zeroed = false;
+    h->walk_zero_keys = nullptr;
+    h->walk_zero_done = nullptr;
+    if (use_tail) {
+        if ((rc = h->w_tail.ensure(tail_kbytes + nq * sizeof(uint32_t))))
+            return rc;
+        h->walk_zero_keys = h->w_tail.as<uint64_t>();
+        h->walk_zero_done = reinterpret_cast<uint32_t *>(h->w_tail.as<char>() + tail_kbytes);
+    }
     // 2. coarse (IndexIVF_HNSW.cpp:248-259)
     const uint32_t *cid = d_coarse_ids;
     const float *cd = d_coarse_dists;
@@ -1241,31 +1265,24 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         cid = h->w_cid.as<uint32_t>();
         cd = h->w_cd.as<float>();
     }
-    // small IVFADC batches: everything behind the coarse stage in one launch (kernels_tail.hip)
     h->tail_wrote_status = false;
-    {
-        static const size_t tail_max_nq = [] {
-            const char *e = getenv("IVFHNSW_TAIL_MAX_NQ");
-            return (e && *e) ? (size_t)atol(e) : (size_t)256;
-        }();
-        if (!h->has_group && nq <= tail_max_nq && !d_out_keys && ivf_tail_supported(h->t, nprobe, (int)k)) {
-            const size_t kbytes = nq * sizeof(uint64_t);
-            if ((rc = h->w_tail.ensure(kbytes + nq * sizeof(uint32_t))))
-                return rc;
-            const int nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
-            StageScope sc(h, IVFHNSW_STAGE_SCAN);
-            HIP_TRY(hipMemsetAsync(h->w_tail.p, 0, kbytes + nq * sizeof(uint32_t), h->stream));
-            HIP_TRY(launch_ivf_tail(h->stream, h->t, xq, cid, cd, (int)nq, nprobe, p->max_codes, nsplit,
-                                    h->w_tail.as<uint64_t>(), reinterpret_cast<uint32_t *>(h->w_tail.as<char>() + kbytes),
-                                    h->w_hdr.as<PlanHdr>(), d_distances, d_labels, h->w_status.as<uint32_t>(),
-                                    h->tail_status_out));
-            h->tail_wrote_status = h->tail_status_out != nullptr;
-            h->last_scan_kernel = "ivf_tail_kernel";
-            h->last_nq = (int)nq;
-            h->last_max_seg = max_seg;
-            h->last_stream = false;
-            return IVFHNSW_OK;
-        }
+    h->walk_zero_keys = nullptr;
+    h->walk_zero_done = nullptr;
+    if (use_tail) {
+        const int nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
+        StageScope sc(h, IVFHNSW_STAGE_SCAN);
+        if (!h->walk_zeroed)
+            HIP_TRY(hipMemsetAsync(h->w_tail.p, 0, tail_kbytes + nq * sizeof(uint32_t), h->stream));
+        HIP_TRY(launch_ivf_tail(h->stream, h->t, xq, cid, cd, (int)nq, nprobe, p->max_codes, nsplit,
+                                h->w_tail.as<uint64_t>(), reinterpret_cast<uint32_t *>(h->w_tail.as<char>() + tail_kbytes),
+                                h->w_hdr.as<PlanHdr>(), d_distances, d_labels, h->w_status.as<uint32_t>(),
+                                h->tail_status_out));
+        h->tail_wrote_status = h->tail_status_out != nullptr;
+        h->last_scan_kernel = "ivf_tail_kernel";
+        h->last_nq = (int)nq;
+        h->last_max_seg = max_seg;
+        h->last_stream = false;
+        return IVFHNSW_OK;
     }
     // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
     {

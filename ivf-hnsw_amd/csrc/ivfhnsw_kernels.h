@@ -136,7 +136,8 @@ bool coarse_latency_supported(const GraphTables &g, int ef);
 size_t coarse_latency_fat_bytes(const GraphTables &g);
 hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat);
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
-                                 uint32_t *coarse_ids, float *coarse_dists, uint32_t *status);
+                                 uint32_t *coarse_ids, float *coarse_dists, uint32_t *status,
+                                 uint64_t *zero_keys = nullptr, uint32_t *zero_done = nullptr); // [nq] words to clear
 // four queries per wavefront (ef <= 256)
 hipError_t launch_coarse4(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                           uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,

@@ -68,7 +68,9 @@ template <int NCH, int NJ, bool STAMPS>
 __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables g, const float *__restrict__ xq, int nq,
                                                                     int nprobe, int ef, uint32_t *__restrict__ coarse_ids,
                                                                     float *__restrict__ coarse_dists,
-                                                                    uint32_t *__restrict__ status, int diag)
+                                                                    uint32_t *__restrict__ status, int diag,
+                                                                    unsigned long long *__restrict__ zero_keys,
+                                                                    uint32_t *__restrict__ zero_done)
 {
     // diag (STAMPS builds only, IVFHNSW_LAT_DIAG=1): the loaders skip their fetch -- results are garbage, what is read
     // off the stamps is the cost of the two barriers alone
@@ -94,6 +96,10 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
         sh->cmd = LAT_CMD_NONE;
         sh->buf = 0;
         sh->touch[0] = sh->touch[1] = LAT_CMD_NONE;
+        if (zero_keys) { // the tail kernel's per-query meeting words (kernels_tail.hip): one launch less per call
+            zero_keys[q] = 0ull;
+            zero_done[q] = 0u;
+        }
     }
     __syncthreads();
 
@@ -563,8 +569,10 @@ hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat)
 }
 
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
-                                 uint32_t *coarse_ids, float *coarse_dists, uint32_t *status)
+                                 uint32_t *coarse_ids, float *coarse_dists, uint32_t *status, uint64_t *zero_keys_u64,
+                                 uint32_t *zero_done)
 {
+    unsigned long long *zero_keys = reinterpret_cast<unsigned long long *>(zero_keys_u64);
     if (nq == 0)
         return hipSuccess;
     if (!coarse_latency_supported(g, ef) || nprobe > ef)
@@ -590,7 +598,7 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
             attr = shm;                                                                                               \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(nq), dim3(LAT_THREADS), shm, s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, \
-                           status, diag);                                                                                   \
+                           status, diag, zero_keys, zero_done);                                                                                   \
     } while (0)
 #define IVFHNSW_LAT_J(N)       \
     do {                       \
