@@ -178,10 +178,13 @@ def merge_streams(streams, lens, cap):
 class ShardedSearcher:
     """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller."""
 
-    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1):
+    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1, force_collectives=False):
         import torch
         self.g, self.rank, self.world, self.nq, self.nprobe, self.group = gpu_index, rank, world, nq, nprobe, group
         self.k = k
+        # run every collective even in a world of one (a single-rank RCCL group accepts them all): lets a one-GPU box
+        # execute the very calls the 8-GPU node makes (tests/test_gpu_rccl_single_rank.py)
+        self.collectives = world > 1 or force_collectives
         self.lo, self.hi, self.per = query_slice(nq, rank, world)
         self.cid = torch.empty((self.per * world, nprobe), dtype=torch.int32, device=device)
         self.cd = torch.empty((self.per * world, nprobe), dtype=torch.float32, device=device)
@@ -198,7 +201,7 @@ class ShardedSearcher:
             g.rotate_dev(self.hi - self.lo, d_q[self.lo:self.hi], self.xrot)
             g.coarse_dev(self.hi - self.lo, self.xrot, self.nprobe, efSearch,
                          self.cid[r * per:], self.cd[r * per:])
-        if self.world > 1:
+        if self.collectives:
             _all_gather_rows(self.cid, r, per, self.group)
             _all_gather_rows(self.cd, r, per, self.group)
 
@@ -217,7 +220,7 @@ class ShardedSearcher:
         heap = heap_order and k > 1
         g.search_dev(nq, k, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
                      d_coarse_dists=self.cd, do_pruning=do_pruning, d_out_keys=self.keys, heap_order=heap)
-        if self.world == 1 and not heap:
+        if not self.collectives and not heap:
             return
         if k == 1:
             _all_reduce(self.keys, dist.ReduceOp.MIN, self.group)
@@ -230,13 +233,13 @@ class ShardedSearcher:
             lmax = lens.max().to(torch.int64).view(1)
             if int(lmax.item()) > cap:
                 raise RuntimeError("candidate stream of a query exceeded %d entries: use ascending order" % cap)
-            if self.world > 1:
+            if self.collectives:
                 _all_reduce(lmax, dist.ReduceOp.MAX, self.group)
             L = max(1, int(lmax.item()))
             mine = torch.empty((nq, L), dtype=torch.int64, device=d_q.device)
             g.last_stream_dev(nq, L, d_keys=mine)
             g.sync()
-            if self.world > 1:
+            if self.collectives:
                 streams = _all_gather_stack(mine, self.group)
                 all_lens = _all_gather_stack(lens, self.group)
             else:
@@ -245,5 +248,5 @@ class ShardedSearcher:
             torch.cuda.current_stream().synchronize()
             g.replay_stream_dev(nq, k, merged, total, merged.shape[1], self.keys)
         g.resolve_keys_dev(nq, k, self.keys, d_dist, d_lab)
-        if self.world > 1:
+        if self.collectives:
             _all_reduce(d_lab, dist.ReduceOp.MAX, self.group)
