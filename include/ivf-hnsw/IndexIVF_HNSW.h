@@ -131,6 +131,17 @@ protected:
     /// (ivfhnsw_gpu_prepare_latency; IVFHNSW_LATENCY=0 keeps the throughput walk)
     void ensure_latency_walk();
     const void *latency_for_;
+    /// IVFHNSW_SHARDS=N: the lists are split list-wise (c % N) over N device handles -- one per GPU of the node, round
+    /// robin when there are fewer -- gpu_ being shard 0; every search is the shard step of SURVEY 8e with the merge done
+    /// on the host (keys are nq * k * 8 bytes per shard).  shards_ holds handles 1 .. N-1.
+    std::vector<ivfhnsw_gpu *> shards_;
+    ivfhnsw_gpu *shard(size_t r) const { return r == 0 ? gpu_ : shards_[r - 1]; }
+    size_t nshards() const { return shards_.size() + 1; }
+    /// every search of the class ends here: one handle, or the sharded step
+    void device_search(size_t nq, size_t k, const float *x, const idx_t *coarse_ids, const float *coarse_dists,
+                       size_t nprobe_, size_t max_codes_, bool pruning, float *distances, long *labels);
+    void upload_graph_to(ivfhnsw_gpu *handle);
+    virtual bool shards_need_graph() const { return false; } ///< Grouping: sub-centroid distances on every shard
 
 private:
     void reconstruct(size_t n, float *x, const float *decoded_residuals, const idx_t *keys);

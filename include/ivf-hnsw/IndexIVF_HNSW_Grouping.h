@@ -41,6 +41,11 @@ public:
     void sync_to_device() override;
 
 protected:
+    bool shards_need_graph() const override { return true; } // sub-centroid distances (Grouping.cpp:248,314) on every shard
+
+public:
+
+protected:
     std::vector<float> query_centroid_dists;
     std::vector<std::vector<float>> inter_centroid_dists;
 

@@ -39,6 +39,8 @@ int ivfhnsw_gpu_abi_version(void);
 /* IndexIVF_HNSW::IndexIVF_HNSW / ~IndexIVF_HNSW (IndexIVF_HNSW.cpp:8-32): device-side state of one
  * index.  `device` is the HIP device ordinal. */
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out);
+/* HIP devices visible to the process (a sharded index puts one handle on each). */
+int ivfhnsw_gpu_device_count(int *count);
 int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h);
 
 /* A second search context on the SAME device tables: own stream, own per-batch workspace, nothing copied.
@@ -171,6 +173,17 @@ int ivfhnsw_gpu_last_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint6
                                 uint32_t *stream_cap);
 int ivfhnsw_gpu_replay_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const uint64_t *d_stream, const uint32_t *d_len,
                                   uint32_t cap, int64_t *d_out_keys);
+
+/* Host-pointer forms of the shard step, for a caller that merges the shards itself in one process (the bundled classes
+ * with IVFHNSW_SHARDS=N: N handles, one per GPU of the node).  search_keys = search_dev with out_keys on host buffers
+ * (the coarse stage must be supplied: it is computed once for all shards); resolve_keys = resolve_keys_dev;
+ * last_stream = last_stream_dev.  All synchronous. */
+int ivfhnsw_gpu_search_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries, const uint32_t *coarse_ids,
+                            const float *coarse_dists, const ivfhnsw_search_params *params, int64_t *keys);
+int ivfhnsw_gpu_resolve_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *keys, float *distances,
+                             int64_t *labels);
+int ivfhnsw_gpu_last_stream(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint64_t *keys, uint32_t *lens,
+                            uint32_t *stream_cap);
 
 /* The coarse stage alone (HierarchicalNSW::searchKnn, hnswalg.cpp:227-234, plus the unload loop of
  * IndexIVF_HNSW.cpp:249-259): device pointers, [nq*nprobe] outputs, nearest first.  Queries must

@@ -27,7 +27,8 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
-    "ivfhnsw_gpu_prepare_latency",
+    "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
+    "ivfhnsw_gpu_device_count",
 )
 
 

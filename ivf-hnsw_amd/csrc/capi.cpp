@@ -127,7 +127,7 @@ struct ivfhnsw_gpu {
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
         w_slen, w_counter, w_tail;
     // staging for the host-pointer entry point
-    DevBuf s_q, s_cid, s_cd, s_dist, s_lab;
+    DevBuf s_q, s_cid, s_cd, s_dist, s_lab, s_keys, s_len;
     HostBuf p_in, p_out; // pinned: small batches
 
     int last_nq = 0, last_max_seg = 0;
@@ -329,6 +329,18 @@ const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
 int ivfhnsw_gpu_abi_version(void) { return 7; }
 
+int ivfhnsw_gpu_device_count(int *count)
+{
+    if (!count)
+        return fail(IVFHNSW_ERR_INVALID, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess)
+        return fail(IVFHNSW_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    *count = n;
+    return IVFHNSW_OK;
+}
+
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
 {
     if (!out)
@@ -377,7 +389,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab, &h->s_keys, &h->s_len};
     for (auto *b : all)
         b->release();
     h->p_in.release();
@@ -1492,6 +1504,80 @@ int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries
     HIP_TRY(hipMemcpyAsync(labels, h->s_lab.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return check_status(h);
+}
+
+int ivfhnsw_gpu_search_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries, const uint32_t *coarse_ids,
+                            const float *coarse_dists, const ivfhnsw_search_params *p, int64_t *keys)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->has_ivf)
+        return fail(IVFHNSW_ERR_STATE, "search before upload_ivf");
+    if (!p || p->nprobe == 0 || k == 0)
+        return fail(IVFHNSW_ERR_INVALID, "nprobe and k must be positive");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!queries || !keys || !coarse_ids || !coarse_dists)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer (a shard is searched with the coarse stage supplied)");
+    const size_t d = h->t.d, np = p->nprobe;
+    if ((rc = h->s_q.ensure(nq * d * sizeof(float))) || (rc = h->s_dist.ensure(nq * k * sizeof(float))) ||
+        (rc = h->s_lab.ensure(nq * k * sizeof(int64_t))) || (rc = h->s_keys.ensure(nq * k * sizeof(int64_t))) ||
+        (rc = h->s_cid.ensure(nq * np * sizeof(uint32_t))) || (rc = h->s_cd.ensure(nq * np * sizeof(float))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->s_q.p, queries, nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_cid.p, coarse_ids, nq * np * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_cd.p, coarse_dists, nq * np * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if ((rc = ivfhnsw_gpu_search_dev(h, nq, k, h->s_q.as<float>(), h->s_cid.as<uint32_t>(), h->s_cd.as<float>(), p,
+                                     h->s_dist.as<float>(), h->s_lab.as<int64_t>(), h->s_keys.as<int64_t>())))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(keys, h->s_keys.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return check_status(h);
+}
+
+int ivfhnsw_gpu_resolve_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *keys, float *distances, int64_t *labels)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!keys || !distances || !labels)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer");
+    if ((rc = h->s_keys.ensure(nq * k * sizeof(int64_t))) || (rc = h->s_dist.ensure(nq * k * sizeof(float))) ||
+        (rc = h->s_lab.ensure(nq * k * sizeof(int64_t))))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(h->s_keys.p, keys, nq * k * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    if ((rc = ivfhnsw_gpu_resolve_keys_dev(h, nq, k, h->s_keys.as<int64_t>(), h->s_dist.as<float>(), h->s_lab.as<int64_t>())))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(distances, h->s_dist.p, nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(labels, h->s_lab.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_last_stream(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint64_t *keys, uint32_t *lens, uint32_t *stream_cap)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (lens) {
+        if ((rc = h->s_len.ensure(nq * sizeof(uint32_t))))
+            return rc;
+        if ((rc = ivfhnsw_gpu_last_stream_dev(h, nq, 0, nullptr, h->s_len.as<uint32_t>(), stream_cap)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(lens, h->s_len.p, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (keys) {
+        if ((rc = h->s_keys.ensure(nq * len_cap * sizeof(uint64_t))))
+            return rc;
+        if ((rc = ivfhnsw_gpu_last_stream_dev(h, nq, len_cap, h->s_keys.as<uint64_t>(), nullptr, stream_cap)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(keys, h->s_keys.p, nq * len_cap * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
 }
 
 int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled)

@@ -56,22 +56,16 @@ void IndexIVF_HNSW_Grouping::sync_to_device()
         if (inter_centroid_dists[c].size() == nsubc)
             std::copy(inter_centroid_dists[c].begin(), inter_centroid_dists[c].end(), icd.begin() + c * nsubc);
     }
-    if (ivfhnsw_gpu_upload_grouping(gpu_, nsubc, alphas.data(), nn.data(), sz.data(), icd.data()))
-        throw std::runtime_error(std::string("ivfhnsw_gpu_upload_grouping: ") + ivfhnsw_gpu_last_error());
+    for (size_t r = 0; r < nshards(); r++)
+        if (ivfhnsw_gpu_upload_grouping(shard(r), nsubc, alphas.data(), nn.data(), sz.data(), icd.data()))
+            throw std::runtime_error(std::string("ivfhnsw_gpu_upload_grouping: ") + ivfhnsw_gpu_last_error());
     device_dirty_ = false;
 }
 
 void IndexIVF_HNSW_Grouping::search_batch(size_t nq, size_t k, const float *x, float *distances, long *labels)
 {
     ensure_device();
-    ivfhnsw_search_params p;
-    p.nprobe = nprobe;
-    p.max_codes = max_codes;
-    p.efSearch = quantizer->efSearch;
-    p.do_pruning = do_pruning ? 1 : 0;
-    p.heap_order = 1;
-    if (ivfhnsw_gpu_search(gpu_, nq, k, x, nullptr, nullptr, &p, distances, reinterpret_cast<int64_t *>(labels)))
-        throw std::runtime_error(std::string("ivfhnsw_gpu_search: ") + ivfhnsw_gpu_last_error());
+    device_search(nq, k, x, nullptr, nullptr, nprobe, max_codes, do_pruning, distances, labels);
 }
 
 void IndexIVF_HNSW_Grouping::search(size_t k, const float *x, float *distances, long *labels)

@@ -7,6 +7,7 @@
 
 #include <ivfhnsw_hip.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -43,6 +44,8 @@ IndexIVF_HNSW::IndexIVF_HNSW(size_t dim, size_t ncentroids, size_t bytes_per_cod
 
 IndexIVF_HNSW::~IndexIVF_HNSW()
 {
+    for (ivfhnsw_gpu *sh : shards_)
+        ivfhnsw_gpu_destroy(sh);
     if (gpu_)
         ivfhnsw_gpu_destroy(gpu_);
     delete quantizer;
@@ -117,6 +120,29 @@ void IndexIVF_HNSW::device_upload_common()
         gpu_fail("ivfhnsw_gpu_create");
     if (do_opq && !opq_matrix)
         throw std::runtime_error("IndexIVF_HNSW: do_opq is set but opq_matrix is null");
+    if (pq->centroids.size() != 256 * d || norm_pq->centroids.size() != 256)
+        throw std::runtime_error("IndexIVF_HNSW: pq / norm_pq have unexpected shapes");
+    // IVFHNSW_SHARDS=N: N handles, shard r on device r % (devices of the node), lists c % N == r
+    static const size_t want_shards = [] {
+        const char *e = getenv("IVFHNSW_SHARDS");
+        const long v = (e && *e) ? atol(e) : 1;
+        return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+    }();
+    if (nshards() != want_shards) {
+        for (ivfhnsw_gpu *sh : shards_)
+            ivfhnsw_gpu_destroy(sh);
+        shards_.clear();
+        int ndev = 1;
+        if (ivfhnsw_gpu_device_count(&ndev) || ndev < 1)
+            gpu_fail("ivfhnsw_gpu_device_count");
+        for (size_t r = 1; r < want_shards; r++) {
+            ivfhnsw_gpu *sh = nullptr;
+            if (ivfhnsw_gpu_create((int)(r % (size_t)ndev), &sh))
+                gpu_fail("ivfhnsw_gpu_create");
+            shards_.push_back(sh);
+        }
+    }
+    const size_t world = nshards();
 
     std::vector<uint64_t> off(nc + 1, 0);
     for (size_t c = 0; c < nc; c++) {
@@ -125,35 +151,43 @@ void IndexIVF_HNSW::device_upload_common()
         off[c + 1] = off[c] + ids[c].size();
     }
     const size_t total = off[nc];
-    std::vector<idx_t> fid(total ? total : 1);
-    std::vector<uint8_t> fcode(total ? total * code_size : 1), fnorm(total ? total : 1);
-    for (size_t c = 0; c < nc; c++) { // list order is scan order (ties): keep it
-        std::copy(ids[c].begin(), ids[c].end(), fid.begin() + off[c]);
-        std::copy(codes[c].begin(), codes[c].end(), fcode.begin() + off[c] * code_size);
-        std::copy(norm_codes[c].begin(), norm_codes[c].end(), fnorm.begin() + off[c]);
+    for (size_t r = 0; r < world; r++) {
+        size_t mine = 0;
+        for (size_t c = r; c < nc; c += world)
+            mine += ids[c].size();
+        std::vector<idx_t> fid(mine ? mine : 1);
+        std::vector<uint8_t> fcode(mine ? mine * code_size : 1), fnorm(mine ? mine : 1);
+        size_t at = 0;
+        for (size_t c = r; c < nc; c += world) { // list order is scan order (ties): keep it
+            std::copy(ids[c].begin(), ids[c].end(), fid.begin() + at);
+            std::copy(codes[c].begin(), codes[c].end(), fcode.begin() + at * code_size);
+            std::copy(norm_codes[c].begin(), norm_codes[c].end(), fnorm.begin() + at);
+            at += ids[c].size();
+        }
+        ivfhnsw_ivf_desc desc;
+        std::memset(&desc, 0, sizeof(desc));
+        desc.d = d;
+        desc.nc = nc;
+        desc.code_size = code_size;
+        desc.offsets = off.data();
+        desc.ids = fid.data();
+        desc.codes = fcode.data();
+        desc.norm_codes = fnorm.data();
+        desc.centroid_norms = centroid_norms.data();
+        desc.pq_centroids = pq->centroids.data();
+        desc.norm_table = norm_pq->centroids.data();
+        desc.opq_A = do_opq ? opq_matrix->A.data() : nullptr;
+        desc.shard_rank = (uint32_t)r;
+        desc.shard_world = (uint32_t)world;
+        desc.list_owner = nullptr;
+        if (ivfhnsw_gpu_upload_ivf(shard(r), &desc))
+            gpu_fail("ivfhnsw_gpu_upload_ivf");
     }
-    ivfhnsw_ivf_desc desc;
-    std::memset(&desc, 0, sizeof(desc));
-    desc.d = d;
-    desc.nc = nc;
-    desc.code_size = code_size;
-    desc.offsets = off.data();
-    desc.ids = fid.data();
-    desc.codes = fcode.data();
-    desc.norm_codes = fnorm.data();
-    desc.centroid_norms = centroid_norms.data();
-    desc.pq_centroids = pq->centroids.data();
-    desc.norm_table = norm_pq->centroids.data();
-    desc.opq_A = do_opq ? opq_matrix->A.data() : nullptr;
-    desc.shard_rank = 0;
-    desc.shard_world = 1;
-    desc.list_owner = nullptr;
-    if (pq->centroids.size() != 256 * d || norm_pq->centroids.size() != 256)
-        throw std::runtime_error("IndexIVF_HNSW: pq / norm_pq have unexpected shapes");
-    if (ivfhnsw_gpu_upload_ivf(gpu_, &desc))
-        gpu_fail("ivfhnsw_gpu_upload_ivf");
 
     upload_graph();
+    if (shards_need_graph())
+        for (ivfhnsw_gpu *sh : shards_)
+            upload_graph_to(sh);
 
     up_pq_ = pq;
     up_norm_pq_ = norm_pq;
@@ -164,6 +198,13 @@ void IndexIVF_HNSW::device_upload_common()
 }
 
 void IndexIVF_HNSW::upload_graph()
+{
+    upload_graph_to(gpu_);
+    graph_dirty_ = false;
+    graph_uploaded_for_ = quantizer;
+}
+
+void IndexIVF_HNSW::upload_graph_to(ivfhnsw_gpu *handle)
 {
     // node records [count][maxM links][d floats] -> three arrays
     const size_t maxM = quantizer->maxM_, n = quantizer->maxelements_;
@@ -176,10 +217,8 @@ void IndexIVF_HNSW::upload_graph()
         std::memcpy(&lnk[i * maxM], rec + 1, (size_t)rec[0] * sizeof(uint32_t));
         std::memcpy(&vec[i * d], quantizer->getDataByInternalId((idx_t)i), d * sizeof(float));
     }
-    if (ivfhnsw_gpu_upload_quantizer(gpu_, n, d, maxM, quantizer->enterpoint_node, cnt.data(), lnk.data(), vec.data()))
+    if (ivfhnsw_gpu_upload_quantizer(handle, n, d, maxM, quantizer->enterpoint_node, cnt.data(), lnk.data(), vec.data()))
         gpu_fail("ivfhnsw_gpu_upload_quantizer");
-    graph_dirty_ = false;
-    graph_uploaded_for_ = quantizer;
 }
 
 void IndexIVF_HNSW::ensure_encoder()
@@ -217,18 +256,152 @@ void IndexIVF_HNSW::assign(size_t n, const float *x, idx_t *labels, size_t k)
         gpu_fail("ivfhnsw_gpu_coarse");
 }
 
-void IndexIVF_HNSW::search_batch(size_t nq, size_t k, const float *x, float *distances, long *labels)
+// Every search of the class: one handle, or -- IVFHNSW_SHARDS=N -- the shard step of SURVEY 8e merged on the host.
+// Keys are the library's packed (orderable distance << 32 | scan position) words, sign-flipped so that a signed
+// minimum picks the reference's winner (smallest distance, earliest scan position on ties).
+namespace {
+const uint64_t kSignFlipH = 0x8000000000000000ull;
+const uint64_t kKeyInitH = (uint64_t)(0x7f7fffffu | 0x80000000u) << 32;
+inline float key_dist(uint64_t ukey)
+{
+    const uint32_t o = (uint32_t)(ukey >> 32);
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
+inline uint64_t key_pack(float dist, uint32_t vpos)
+{
+    uint32_t u;
+    std::memcpy(&u, &dist, sizeof(u));
+    const uint32_t o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)o << 32) | vpos;
+}
+} // namespace
+
+void IndexIVF_HNSW::device_search(size_t nq, size_t k, const float *x, const idx_t *coarse_ids, const float *coarse_dists,
+                                  size_t nprobe_, size_t max_codes_, bool pruning, float *distances, long *labels)
 {
     static_assert(sizeof(long) == sizeof(int64_t), "LP64 expected");
-    ensure_device();
     ivfhnsw_search_params p;
-    p.nprobe = nprobe;
-    p.max_codes = max_codes;
+    p.nprobe = nprobe_;
+    p.max_codes = max_codes_;
     p.efSearch = quantizer->efSearch;
-    p.do_pruning = 0;
+    p.do_pruning = pruning ? 1 : 0;
     p.heap_order = 1; // k > 1: the array faiss's max-heap leaves, as the reference returns it
-    if (ivfhnsw_gpu_search(gpu_, nq, k, x, nullptr, nullptr, &p, distances, reinterpret_cast<int64_t *>(labels)))
-        gpu_fail("ivfhnsw_gpu_search");
+    if (shards_.empty()) {
+        if (ivfhnsw_gpu_search(gpu_, nq, k, x, coarse_ids, coarse_dists, &p, distances, reinterpret_cast<int64_t *>(labels)))
+            gpu_fail("ivfhnsw_gpu_search");
+        return;
+    }
+    if (nq == 0)
+        return;
+    const size_t world = nshards();
+    // the coarse stage once, on shard 0 (the rotated query walks the rotated graph, IndexIVF_HNSW.cpp:240,248)
+    std::vector<idx_t> cid_own;
+    std::vector<float> cd_own;
+    if (!coarse_ids) {
+        std::vector<float> xr;
+        const float *q = x;
+        if (do_opq) {
+            xr.resize(nq * d);
+            opq_matrix->apply_noalloc((long)nq, x, xr.data());
+            q = xr.data();
+        }
+        cid_own.resize(nq * nprobe_);
+        cd_own.resize(nq * nprobe_);
+        if (ivfhnsw_gpu_coarse(gpu_, nq, q, nprobe_, quantizer->efSearch, cid_own.data(), cd_own.data()))
+            gpu_fail("ivfhnsw_gpu_coarse");
+        coarse_ids = cid_own.data();
+        coarse_dists = cd_own.data();
+    }
+    const bool heap = k > 1;
+    p.heap_order = heap ? 1 : 0;
+    std::vector<std::vector<int64_t>> keys(world, std::vector<int64_t>(nq * k));
+    std::vector<std::string> err(world);
+    // one host thread per shard: every handle has its own device and stream
+#pragma omp parallel for schedule(static, 1)
+    for (long r = 0; r < (long)world; r++)
+        if (ivfhnsw_gpu_search_keys(shard((size_t)r), nq, k, x, coarse_ids, coarse_dists, &p, keys[(size_t)r].data()))
+            err[(size_t)r] = ivfhnsw_gpu_last_error();
+    for (const auto &e : err)
+        if (!e.empty())
+            throw std::runtime_error("ivfhnsw_gpu_search_keys: " + e);
+    std::vector<int64_t> merged(nq * k);
+    if (!heap) {
+        // k = 1: the smallest key over the shards
+        for (size_t i = 0; i < nq; i++) {
+            int64_t m = keys[0][i];
+            for (size_t r = 1; r < world; r++)
+                m = keys[r][i] < m ? keys[r][i] : m;
+            merged[i] = m;
+        }
+    } else {
+        // k > 1, the reference's heap ARRAY (IndexIVF_HNSW.cpp:265,285-288): the shards' candidate streams -- supersets
+        // of what faiss's heap admits, each in its scan order -- merged by scan position and replayed through the very
+        // maxheap_pop / maxheap_push the reference calls; a code failing `dist < distances[0]` leaves the heap untouched
+        std::vector<std::vector<uint32_t>> lens(world, std::vector<uint32_t>(nq));
+        uint32_t cap = 0, lmax = 1;
+        for (size_t r = 0; r < world; r++) {
+            if (ivfhnsw_gpu_last_stream(shard(r), nq, 0, nullptr, lens[r].data(), &cap))
+                gpu_fail("ivfhnsw_gpu_last_stream");
+            for (uint32_t l : lens[r]) {
+                if (l > cap)
+                    throw std::runtime_error("IndexIVF_HNSW: candidate stream of a query exceeded the device buffer "
+                                             "(k / max_codes too large for heap-array order across shards)");
+                lmax = l > lmax ? l : lmax;
+            }
+        }
+        std::vector<std::vector<uint64_t>> streams(world, std::vector<uint64_t>(nq * (size_t)lmax));
+        for (size_t r = 0; r < world; r++)
+            if (ivfhnsw_gpu_last_stream(shard(r), nq, lmax, streams[r].data(), nullptr, &cap))
+                gpu_fail("ivfhnsw_gpu_last_stream");
+        std::vector<uint64_t> all;
+        std::vector<float> hv(k);
+        std::vector<long> hp(k);
+        for (size_t i = 0; i < nq; i++) {
+            all.clear();
+            for (size_t r = 0; r < world; r++)
+                all.insert(all.end(), streams[r].begin() + i * lmax, streams[r].begin() + i * lmax + lens[r][i]);
+            std::sort(all.begin(), all.end(),
+                      [](uint64_t a, uint64_t b) { return (uint32_t)a < (uint32_t)b; }); // scan order
+            faiss::maxheap_heapify(k, hv.data(), hp.data());
+            for (uint64_t ukey : all) {
+                const float dj = key_dist(ukey);
+                if (dj < hv[0]) {
+                    faiss::maxheap_pop(k, hv.data(), hp.data());
+                    faiss::maxheap_push(k, hv.data(), hp.data(), dj, (long)(uint32_t)ukey);
+                }
+            }
+            for (size_t j = 0; j < k; j++)
+                merged[i * k + j] =
+                    (int64_t)((hp[j] < 0 ? kKeyInitH : key_pack(hv[j], (uint32_t)hp[j])) ^ kSignFlipH);
+        }
+    }
+    // every shard resolves the labels it owns (-1 elsewhere): the maximum is the label
+    std::vector<std::vector<long>> lab(world, std::vector<long>(nq * k));
+    std::vector<std::vector<float>> dis(world, std::vector<float>(nq * k));
+#pragma omp parallel for schedule(static, 1)
+    for (long r = 0; r < (long)world; r++)
+        if (ivfhnsw_gpu_resolve_keys(shard((size_t)r), nq, k, merged.data(), dis[(size_t)r].data(),
+                                     reinterpret_cast<int64_t *>(lab[(size_t)r].data())))
+            err[(size_t)r] = ivfhnsw_gpu_last_error();
+    for (const auto &e : err)
+        if (!e.empty())
+            throw std::runtime_error("ivfhnsw_gpu_resolve_keys: " + e);
+    for (size_t i = 0; i < nq * k; i++) {
+        long l = lab[0][i];
+        for (size_t r = 1; r < world; r++)
+            l = lab[r][i] > l ? lab[r][i] : l;
+        labels[i] = l;
+        distances[i] = dis[0][i];
+    }
+}
+
+void IndexIVF_HNSW::search_batch(size_t nq, size_t k, const float *x, float *distances, long *labels)
+{
+    ensure_device();
+    device_search(nq, k, x, nullptr, nullptr, nprobe, max_codes, false, distances, labels);
 }
 
 void IndexIVF_HNSW::search(size_t k, const float *x, float *distances, long *labels)
@@ -264,9 +437,7 @@ void IndexIVF_HNSW::search_debug(size_t k, const float *x, float *distances, lon
         std::cout << "centroid " << cid[i] << " with query distance of " << cd[i] << std::endl;
         std::cout << "group size: " << norm_codes[cid[i]].size() << std::endl;
     }
-    ivfhnsw_search_params p = {nprobe, max_codes, quantizer->efSearch, 0, 1};
-    if (ivfhnsw_gpu_search(gpu_, 1, k, x, cid.data(), cd.data(), &p, distances, reinterpret_cast<int64_t *>(labels)))
-        gpu_fail("ivfhnsw_gpu_search");
+    device_search(1, k, x, cid.data(), cd.data(), nprobe, max_codes, false, distances, labels);
 }
 
 IndexIVF_HNSW::idx_t IndexIVF_HNSW::search_enn(const float *x, float *distances, long *labels)
@@ -284,9 +455,7 @@ IndexIVF_HNSW::idx_t IndexIVF_HNSW::search_enn(const float *x, float *distances,
     if (ivfhnsw_gpu_coarse(gpu_, 1, q, 1, quantizer->efSearch ? quantizer->efSearch : 1, &cid, &cd))
         gpu_fail("ivfhnsw_gpu_coarse");
     std::cout << "Get centroid in ENN: " << cid << std::endl;
-    ivfhnsw_search_params p = {1, max_codes, quantizer->efSearch, 0, 1};
-    if (ivfhnsw_gpu_search(gpu_, 1, 1, x, &cid, &cd, &p, distances, reinterpret_cast<int64_t *>(labels)))
-        gpu_fail("ivfhnsw_gpu_search");
+    device_search(1, 1, x, &cid, &cd, 1, max_codes, false, distances, labels);
     return cid;
 }
 
@@ -294,10 +463,7 @@ void IndexIVF_HNSW::search2(size_t k, const float *x, float *distances, long *la
                             idx_t *centroid_idxs)
 {
     ensure_device();
-    ivfhnsw_search_params p = {nprobe, max_codes, quantizer->efSearch, 0, 1};
-    if (ivfhnsw_gpu_search(gpu_, 1, k, x, centroid_idxs, query_centroid_dists, &p, distances,
-                           reinterpret_cast<int64_t *>(labels)))
-        gpu_fail("ivfhnsw_gpu_search");
+    device_search(1, k, x, centroid_idxs, query_centroid_dists, nprobe, max_codes, false, distances, labels);
 }
 
 void IndexIVF_HNSW::search2m(size_t k, const float *x, float *distances[], long *labels[],
@@ -305,12 +471,8 @@ void IndexIVF_HNSW::search2m(size_t k, const float *x, float *distances[], long 
 {
     // one result heap per probe (the reference's variant is racy; this one is well defined): probe i alone
     ensure_device();
-    for (size_t i = 0; i < nprobe; i++) {
-        ivfhnsw_search_params p = {1, (size_t)-1, quantizer->efSearch, 0, 1};
-        if (ivfhnsw_gpu_search(gpu_, 1, k, x, centroid_idxs + i, query_centroid_dists + i, &p, distances[i],
-                               reinterpret_cast<int64_t *>(labels[i])))
-            gpu_fail("ivfhnsw_gpu_search");
-    }
+    for (size_t i = 0; i < nprobe; i++)
+        device_search(1, k, x, centroid_idxs + i, query_centroid_dists + i, 1, (size_t)-1, false, distances[i], labels[i]);
 }
 
 void IndexIVF_HNSW::trace_centroids(size_t idx_q, bool missed)

@@ -19,9 +19,10 @@ TOOL = os.path.join(ROOT, "tests", "cpp", "hostlib_tool.bin")
 REF_DRV = os.path.join(ROOT, "oracle", "_ref")
 
 
-def tool(*args):
+def tool(*args, extra_env=None):
     assert os.path.exists(TOOL), "run __graft_entry__.build()"
     env = dict(os.environ)
+    env.update(extra_env or {})
     env.setdefault("OMP_NUM_THREADS", str(min(8, len(os.sched_getaffinity(0)))))  # a CPU quota makes wide teams crawl
     env.setdefault("OMP_WAIT_POLICY", "passive")
     r = subprocess.run([TOOL] + [str(a) for a in args], capture_output=True, text=True, env=env)
@@ -113,13 +114,13 @@ def test_reference_drivers_compile_unchanged_against_these_headers():
 
 
 # ---------------------------------------------------------------------------------------------- search (GPU)
-def _class_search(tmp_path, c, nprobe, max_codes, ef, pruning, k=1):
+def _class_search(tmp_path, c, nprobe, max_codes, ef, pruning, k=1, extra_env=None):
     p = hostio.dump_corpus(c, str(tmp_path))
     out = str(tmp_path / "res.bin")
     nq = len(c["queries"])
     tool("search", "grouping" if c["nsubc"] else "ivf", c["d"], c["nc"], c["code_size"], c["nsubc"], p["centroids"],
          p["info"], p["edges"], p["pq"], p["norm_pq"], p["opq"], p["index"], p["queries"], nq, k, nprobe, max_codes, ef,
-         int(pruning), out)
+         int(pruning), out, extra_env=extra_env)
     raw = np.fromfile(out, np.uint8)
     lab = raw[:2 * nq * k * 8].view(np.int64).reshape(2, nq, k)
     dist = raw[2 * nq * k * 8:].view(np.float32).reshape(2, nq, k)
@@ -160,8 +161,31 @@ def test_class_search_k10_returns_the_reference_heap_array(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opq,k", [(False, 1), (True, 1), (False, 5)])
-def test_class_sibling_entry_points_equal_oracle(tmp_path, opq, k):
+@pytest.mark.parametrize("shards", [2, 5])
+@pytest.mark.parametrize("kw,nprobe,max_codes,ef,pruning,k", [
+    (dict(seed=72, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80, opq=True), 8, 1500, 32, False, 1),
+    (dict(seed=73, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80, nsubc=8), 8, 700, 40, True, 1),
+    (dict(seed=71, nc=128, d=128, M=16, n_base=8000, nq=32, efConstruction=80), 8, 1500, 32, False, 10),
+    (dict(seed=74, nc=128, d=96, M=8, n_base=6000, nq=32, efConstruction=80, nsubc=8, opq=True), 8, 900, 40, False, 7),
+])
+def test_class_search_on_list_shards_equals_oracle(tmp_path, shards, kw, nprobe, max_codes, ef, pruning, k):
+    """IVFHNSW_SHARDS=N: the classes split the lists list-wise over N device handles (one per GPU of a node; here all
+    on GPU 0) and every search() / search_batch() is the shard step of SURVEY 8e merged on the host -- k = 1 by the
+    smallest key, k > 1 by replaying faiss's heap over the shards' candidate streams merged in scan order.  The
+    reference's drivers reach the multi-GPU split through this without a line changed."""
+    c = synth.make_corpus(**kw)
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=pruning)
+    ref_d, ref_l, _, _, _ = ox.search_batch(c["queries"], k=k)
+    lab, dist = _class_search(tmp_path, c, nprobe, max_codes, ef, pruning, k=k, extra_env={"IVFHNSW_SHARDS": str(shards)})
+    for mode in (0, 1):  # search() per query, search_batch()
+        assert np.array_equal(lab[mode], ref_l)
+        assert np.array_equal(dist[mode].view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opq,k,shards", [(False, 1, 1), (True, 1, 1), (False, 5, 1), (True, 5, 3)])
+def test_class_sibling_entry_points_equal_oracle(tmp_path, opq, k, shards):
     """search_debug, search_enn, search2 and search2m (IndexIVF_HNSW.cpp:328-534) through the class surface.
     search_debug == search; search_enn == the search with nprobe 1 and k 1; search2 == the search on the caller's
     coarse stage (here the HOST walk of the class's quantizer, which must equal the oracle's walk); search2m == one
@@ -173,7 +197,8 @@ def test_class_sibling_entry_points_equal_oracle(tmp_path, opq, k):
     p = hostio.dump_corpus(c, str(tmp_path))
     out = str(tmp_path / "sib.bin")
     tool("siblings", "ivf", c["d"], c["nc"], c["code_size"], 0, p["centroids"], p["info"], p["edges"], p["pq"],
-         p["norm_pq"], p["opq"], p["index"], p["queries"], nq, k, nprobe, max_codes, ef, 0, out)
+         p["norm_pq"], p["opq"], p["index"], p["queries"], nq, k, nprobe, max_codes, ef, 0, out,
+         extra_env={"IVFHNSW_SHARDS": str(shards)})
     raw = np.fromfile(out, np.uint8)
     n_lab = nq * k + nq + nq * k + nq * nprobe * k
     lab = raw[:n_lab * 8].view(np.int64)
