@@ -28,7 +28,18 @@ def test_single_query_latency_is_reported(gpu, capsys):
     t0 = time.perf_counter()
     g.search(q, 1, 32, 10000, efSearch=80)
     batch = time.perf_counter() - t0
+    # the latency form of the walk (what the classes' search() prepares): same answers, fewer microseconds
+    d_ref, l_ref = g.search(q, 1, 32, 10000, efSearch=80)
+    g.prepare_latency()
+    for x in q[:20]:
+        g.search(x, 1, 32, 10000, efSearch=80)
+    t0 = time.perf_counter()
+    for i, x in enumerate(q):
+        d1, l1 = g.search(x, 1, 32, 10000, efSearch=80)
+        assert l1[0, 0] == l_ref[i, 0] and d1[0, 0] == d_ref[i, 0]
+    per_call_lat = (time.perf_counter() - t0) / len(q)
     with capsys.disabled():
-        print("\n[latency] one query per call: %.0f us/query; one call for %d queries: %.0f us/query"
-              % (per_call * 1e6, len(q), batch / len(q) * 1e6))
-    assert per_call < 0.05
+        print("\n[latency] one query per call: %.0f us/query (throughput walk), %.0f us/query (latency walk, results "
+              "checked); one call for %d queries: %.0f us/query"
+              % (per_call * 1e6, per_call_lat * 1e6, len(q), batch / len(q) * 1e6))
+    assert per_call < 0.05 and per_call_lat < per_call
