@@ -715,6 +715,11 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
             return (e && atoi(e) == 0) ? 0 : 1;
         }();
         h->gr.merge_admissions = merge;
+        static const int skippad = [] {
+            const char *e = getenv("IVFHNSW_WALK_SKIPPAD");
+            return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : 1;
+        }();
+        h->gr.skip_padding = skippad;
     }
     {
         // IVFHNSW_WALK_LATE_VISIT: 1 always, 0 never, unset = where it pays -- graphs whose ids need more than 8 tag

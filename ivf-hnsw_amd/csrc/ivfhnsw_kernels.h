@@ -81,6 +81,7 @@ struct GraphTables {
     // per node 32 rows of d floats (zero beyond the link count) and a 256-byte trailer with its links and link count;
     // NULL until ivfhnsw_gpu_prepare_latency builds it.
     const float *fat;
+    int skip_padding;     // walk: the filter skips the arithmetic of rows beyond the link count (A/B knob IVFHNSW_WALK_SKIPPAD)
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
     int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
 };

@@ -510,10 +510,18 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     const uint4 b = *reinterpret_cast<const uint4 *>(s_q8 + 96 + 4 * (lane & 7));
                     xh[0] = b.x, xh[1] = b.y, xh[2] = b.z, xh[3] = b.w;
                 }
+                const int cnt_s = __builtin_amdgcn_readfirstlane(cnt);
                 for (int rb = 0;;) {
                     int S[4], X[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
+                        // rows at and beyond the link count are zero padding whose verdicts nobody reads (mean degree
+                        // 21 of 32 slots): a scalar branch over their arithmetic (IVFHNSW_WALK_SKIPPAD, A/B knob)
+                        if (g.skip_padding && rb + 8 * i >= cnt_s) {
+                            S[i] = 0;
+                            X[i] = 0;
+                            continue;
+                        }
                         // 128 * (row.row - 2 (Q/256).row), exact in integers; 128 * Q.Q / 65536 joins below
                         const uint32_t ws[4] = {nw[i].x, nw[i].y, nw[i].z, nw[i].w};
                         uint32_t hr = 0, rr = 0;
