@@ -113,7 +113,7 @@ struct ivfhnsw_gpu {
     DevBuf g_alpha, g_nn, g_sizes, g_inter;
     GroupTables g{};
     bool has_group = false;
-    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms, q_fat;
+    DevBuf q_counts, q_links, q_vectors, q_qrows, q_nbrows, q_nbnorms, q_fat, q_links_c;
     GraphTables gr{};
     bool has_graph = false;
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
@@ -387,7 +387,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     for (auto e : h->pool)
         (void)hipEventDestroy(e);
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
-                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
+                     &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->q_links_c, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
                      &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab, &h->s_keys, &h->s_len};
     for (auto *b : all)
@@ -622,7 +622,7 @@ static int build_neighbour_rows(ivfhnsw_gpu *h)
         const char *e = getenv("IVFHNSW_WALK_NBROWS_GIB");
         return e ? atof(e) : 48.0;
     }();
-    if (!h->gr.qrows || mode != 2 || h->gr.d > 128)
+    if (!h->gr.qrows || mode != 2 || h->gr.d > 128 || h->gr.n >= (1u << 24) || h->gr.maxM > 64)
         return IVFHNSW_OK;
     const int nb_rows = (h->gr.maxM + 31) & ~31;
     const size_t bytes = (size_t)h->gr.n * nb_rows * 128;
@@ -633,10 +633,14 @@ static int build_neighbour_rows(ivfhnsw_gpu *h)
         return rc;
     if ((rc = h->q_nbnorms.ensure((size_t)h->gr.n * nb_rows * sizeof(uint32_t))))
         return rc;
-    HIP_TRY(launch_build_nbrows(h->stream, h->gr, h->q_nbrows.as<uint8_t>(), h->q_nbnorms.as<uint32_t>(), nb_rows));
+    if ((rc = h->q_links_c.ensure((size_t)h->gr.n * h->gr.maxM * sizeof(uint32_t))))
+        return rc;
+    HIP_TRY(launch_build_nbrows(h->stream, h->gr, h->q_nbrows.as<uint8_t>(), h->q_nbnorms.as<uint32_t>(), nb_rows,
+                                h->q_links_c.as<uint32_t>()));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->gr.nbrows = h->q_nbrows.as<uint8_t>();
     h->gr.nbnorms = h->q_nbnorms.as<uint32_t>();
+    h->gr.links_c = h->q_links_c.as<uint32_t>();
     h->gr.nb_rows = nb_rows;
     return IVFHNSW_OK;
 }
@@ -737,6 +741,7 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
     h->gr.qrows = nullptr;
     h->gr.nbrows = nullptr;
     h->gr.nbnorms = nullptr;
+    h->gr.links_c = nullptr;
     h->gr.nb_rows = 0;
     h->gr.q_lo = 0.f;
     h->gr.q_step = 1.f;
@@ -1651,7 +1656,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
         return fail(IVFHNSW_ERR_INVALID, "null argument");
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
-                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
+                           &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->q_links_c, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
                            &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;

@@ -76,6 +76,7 @@ struct GraphTables {
     // nb_rows*128-byte read per expansion, issued together with the link list.  NULL = gather from qrows.
     const uint8_t *nbrows;
     const uint32_t *nbnorms; // [n][nb_rows] sum of bytes^2 of every neighbour row (the filter's ||c||^2 term)
+    const uint32_t *links_c; // [n][maxM] id | (link count of id) << 24; goes with nbrows: the walk's keys carry the count
     int nb_rows;
     // Latency form of the walk (kernels_hnsw_lat.hip): node i carries the FLOAT rows of its own neighbours,
     // per node 32 rows of d floats (zero beyond the link count) and a 256-byte trailer with its links and link count;
@@ -174,7 +175,8 @@ hipError_t launch_group_alpha(hipStream_t s, const unsigned long long *offsets, 
 hipError_t launch_group_rows(hipStream_t s, const unsigned long long *offsets, const uint32_t *sub, uint32_t *rows,
                              size_t ngroups, int nsubc);
 // nbrows[i][j] = qrows[links[i][j]] for j < counts[i], zero otherwise (GraphTables::nbrows)
-hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows);
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows,
+                               uint32_t *links_c);
 hipError_t launch_fill_bytes(hipStream_t s, uint8_t *dst, size_t nbytes, uint64_t seed);
 hipError_t launch_fill_iota(hipStream_t s, uint32_t *dst, size_t n, uint32_t first);
 hipError_t launch_fill_lists(hipStream_t s, const IvfTables &t, uint8_t *codes, uint8_t *norm_codes, uint32_t *ids,

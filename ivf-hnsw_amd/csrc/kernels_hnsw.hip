@@ -233,6 +233,15 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     // 1.085 -> 1.103 ms at 2^17 nodes, where the load's wait costs more than the instructions -- so it goes with
     // the form large graphs take.
     constexpr bool ROWNORMS = FMODE == 3;
+    // Neighbour-row forms: a node's LINK COUNT travels with its id.  A node's record is nb_rows byte rows but the mean
+    // degree is ~21 of 32: a third of the 4-KB read is zero padding, and the walk moves ~63 % of the HBM peak, so those
+    // bytes are time.  The count only used to arrive together with the record.  Here the "id" of every key is
+    // id << 7 | count (the count is a function of the id, so the (dist, id) order is the reference's; ids stay below 2^24)
+    // and the link table carries id | count << 24 (GraphTables::links_c, built with the rows): when a node is popped its
+    // count is already in a scalar register, and only the rows below it are fetched.
+    constexpr bool CK = FMODE >= 2;
+    auto enc_id = [](uint32_t id, uint32_t c) { return CK ? (id << 7) | c : id; };
+    auto dec_id = [](uint32_t e) { return CK ? e >> 7 : e; };
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
     bool bitmap_dirty = true; // the bitmap must be wiped before its first use and after any query that used it
 
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             const float d0 = l2_ref_order_quad(g.vectors + (size_t)g.enterpoint * g.d, s_q, g.d, lane & 3);
             bool ub = false;
             if (lane == 0) {
-                R.r[0] = mk_key(d0, g.enterpoint);
+                R.r[0] = mk_key(d0, enc_id(g.enterpoint, CK ? (uint32_t)g.counts[g.enterpoint] : 0u));
                 (void)visit_test_and_set<TAGW, NB>(g.enterpoint, vt, bm, ub);
             }
             __syncthreads();
@@ -446,21 +455,43 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 st_acc[5] += 1;
             }
             // ---- expand: links, visited test-and-set, distances (hnswalg.cpp:72-91)
-            const uint32_t node = pick_id;
-            const int cnt = g.counts[node];
-            uint32_t nb = 0;
-            if (lane < g.maxM)
-                nb = g.links[(size_t)node * g.maxM + lane]; // issued together with the count
+            const uint32_t node = dec_id(pick_id);
+            int cnt;
+            uint32_t nb = 0, nb_enc = 0; // neighbour id, and the "id" its key will carry
+            if constexpr (CK) {
+                cnt = (int)(pick_id & 127u); // scalar: known before anything of the record is read
+                if (lane < g.maxM) {
+                    const uint32_t raw = g.links_c[(size_t)node * g.maxM + lane];
+                    nb = raw & 0xffffffu;
+                    nb_enc = (nb << 7) | (raw >> 24);
+                }
+            } else {
+                cnt = g.counts[node];
+                if (lane < g.maxM)
+                    nb = g.links[(size_t)node * g.maxM + lane]; // issued together with the count
+                nb_enc = nb;
+            }
             // neighbour byte rows of this node (exact rejection filter, below): rows 8i + (lane >> 3), 16-byte
             // chunk lane & 7 -- four 1 KiB wave reads, in flight together with the link list
             const bool filter_now = prefilter && n == ef;
             uint4 nw[4] = {};
             uint32_t row_rr = 0; // sum of bytes^2 of the row this lane will judge (row 8 * (2 bit2 + bit0) + group)
             if (filter_now && inline_rows) {
-                const uint4 *nbr = reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + lane;
+                if constexpr (CK) {
+                    // rows below the count only: a lane whose row is padding re-reads the last real row's chunk (same
+                    // cache lines, no branch; nobody reads its verdict), an 8-row group wholly beyond it is skipped
+                    const uint4 *nbr = reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + (lane & 7);
+                    const int last = max(cnt - 1, 0);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    nw[i] = nbr[i * 64];
+                    for (int i = 0; i < 4; i++)
+                        if (8 * i < cnt)
+                            nw[i] = nbr[min(8 * i + (lane >> 3), last) * 8];
+                } else {
+                    const uint4 *nbr = reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        nw[i] = nbr[i * 64];
+                }
                 if constexpr (ROWNORMS)
                     row_rr = g.nbnorms[(size_t)node * g.nb_rows + judged_row];
             }
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     for (int i = 0; i < 4; i++) {
                         // rows at and beyond the link count are zero padding whose verdicts nobody reads (mean degree
                         // 21 of 32 slots): a scalar branch over their arithmetic (IVFHNSW_WALK_SKIPPAD, A/B knob)
-                        if (g.skip_padding && rb + 8 * i >= cnt_s) {
+                        if ((CK || g.skip_padding) && rb + 8 * i >= cnt_s) {
                             S[i] = 0;
                             X[i] = 0;
                             continue;
@@ -578,11 +609,21 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     rb += 32;
                     if (rb >= cnt)
                         break;
-                    const uint4 *nbr =
-                        reinterpret_cast<const uint4 *>(g.nbrows + ((size_t)node * g.nb_rows + rb) * 128) + lane;
+                    if constexpr (CK) {
+                        const uint4 *nbr =
+                            reinterpret_cast<const uint4 *>(g.nbrows + (size_t)node * g.nb_rows * 128) + (lane & 7);
+                        const int last = max(cnt - 1, 0);
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        nw[i] = nbr[i * 64];
+                        for (int i = 0; i < 4; i++)
+                            if (rb + 8 * i < cnt)
+                                nw[i] = nbr[min(rb + 8 * i + (lane >> 3), last) * 8];
+                    } else {
+                        const uint4 *nbr =
+                            reinterpret_cast<const uint4 *>(g.nbrows + ((size_t)node * g.nb_rows + rb) * 128) + lane;
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            nw[i] = nbr[i * 64];
+                    }
                     if constexpr (ROWNORMS)
                         row_rr = g.nbnorms[(size_t)node * g.nb_rows + rb + judged_row];
                 }
@@ -635,7 +676,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 const int r = base + (lane >> 3);
                 const bool active = r < nfresh;
                 const int src = take8_set_bits(rest, lane); // the r-th fresh link lane (0 beyond the last)
-                const uint32_t nbq = (uint32_t)__shfl((int)nb, src, 64);
+                const uint32_t nbe = (uint32_t)__shfl((int)nb_enc, src, 64); // what the key carries (id with its count)
+                const uint32_t nbq = dec_id(nbe);
                 float dq = 0.f;
                 if (active) {
                     if constexpr (QREG)
@@ -672,7 +714,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     // set entry among the candidates, scatter through LDS, look at the boundary; a tie there
                     // leaves the registers untouched and takes the sequential path.
                     const bool is_cand = (cand >> lane) & 1ull;
-                    const unsigned long long Kc = mk_key(dq, nbq);
+                    const unsigned long long Kc = mk_key(dq, nbe);
                     int dn[NCH]; // candidates ABOVE this lane's set entries (an add-with-carry per compare)
 #pragma unroll
                     for (int cc = 0; cc < NCH; cc++)
@@ -723,7 +765,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     const int b = __ffsll((long long)cand) - 1;
                     cand &= cand - 1;
                     const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(dq), b));
-                    const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nbq, b);
+                    const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)nbe, b);
                     const unsigned long long oldtop = topk;
                     if (!(__uint_as_float(key_dist_bits(oldtop)) > dj || n < ef))
                         continue;
@@ -773,7 +815,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             const int i = cc * 64 + lane;
             if (i < nprobe) {
                 const bool have = ntail >= 0 && i < n;
-                coarse_ids[(size_t)q * nprobe + i] = have ? key_id(R.r[cc]) : 0xffffffffu;
+                coarse_ids[(size_t)q * nprobe + i] = have ? dec_id(key_id(R.r[cc])) : 0xffffffffu;
                 coarse_dists[(size_t)q * nprobe + i] = have ? __uint_as_float(key_dist_bits(R.r[cc])) : 0.f;
             }
         }
@@ -787,10 +829,20 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 // ... and the rows' squared norms (sum of bytes^2, u32 [n][nb_rows]): the walk's filter needs them per row, and a
 // dword load per row is cheaper there than sixteen v_dot4 of the row with itself
 __global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t *__restrict__ nbrows,
-                                                          uint32_t *__restrict__ nbnorms, int nb_rows)
+                                                          uint32_t *__restrict__ nbnorms, int nb_rows,
+                                                          uint32_t *__restrict__ links_c)
 {
     const size_t node = blockIdx.x;
     const int cnt = g.counts[node];
+    // ... and the link table whose entries carry the link count of the node they name (GraphTables::links_c)
+    if ((int)threadIdx.x < g.maxM) {
+        uint32_t e = 0;
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t id = g.links[node * g.maxM + threadIdx.x];
+            e = id | ((uint32_t)g.counts[id] << 24);
+        }
+        links_c[node * g.maxM + threadIdx.x] = e;
+    }
     const int cpr = g.d >> 4; // 16-byte chunks per source row (<= 8)
     for (int r0 = 0; r0 < nb_rows; r0 += 8) {
         const int r = r0 + (threadIdx.x >> 3), c = threadIdx.x & 7;
@@ -809,11 +861,12 @@ __global__ __launch_bounds__(64) void build_nbrows_kernel(GraphTables g, uint8_t
     }
 }
 
-hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows)
+hipError_t launch_build_nbrows(hipStream_t s, const GraphTables &g, uint8_t *nbrows, uint32_t *nbnorms, int nb_rows,
+                               uint32_t *links_c)
 {
-    if (!g.qrows || g.d > 128 || (g.d & 15) || nb_rows < g.maxM || (nb_rows & 31))
+    if (!g.qrows || g.d > 128 || (g.d & 15) || nb_rows < g.maxM || (nb_rows & 31) || g.n >= (1u << 24) || g.maxM > 64)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(build_nbrows_kernel, dim3(g.n), dim3(64), 0, s, g, nbrows, nbnorms, nb_rows);
+    hipLaunchKernelGGL(build_nbrows_kernel, dim3(g.n), dim3(64), 0, s, g, nbrows, nbnorms, nb_rows, links_c);
     return hipGetLastError();
 }
 
