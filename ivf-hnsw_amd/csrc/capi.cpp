@@ -1329,8 +1329,15 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     // k = 1 on the common shapes: table and scan fused, the table never leaves the chip (kernels_scan2.hip)
     const bool short_segments = seg_hint > 0 && seg_hint <= 48;
     const bool fused = k == 1 && scan_fused_supported(h->t, short_segments);
+    // small batches: split each query over several workgroups so the chip still fills
+    int nsplit = 1;
+    if (k == 1 && nq < 1024)
+        nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
+    // list shards: table and scan in one software-pipelined kernel, the table never leaves the chip (kernels_scan3.hip)
+    const bool pipe = k == 1 && !fused && !h->has_group && !heap &&
+                      scan_pipe_supported(h->t, max_seg, (int)nq, nsplit, h->n_local > 0);
     // 4. table (IndexIVF_HNSW.cpp:262)
-    if (!fused) {
+    if (!fused && !pipe) {
         if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
             return rc;
         StageScope sc(h, IVFHNSW_STAGE_LUT);
@@ -1346,10 +1353,6 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
             return rc;
     }
     {
-        // small batches: split each query over several workgroups so the chip still fills
-        int nsplit = 1;
-        if (k == 1 && nq < 1024)
-            nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
         if (fused && (rc = h->w_counter.ensure(sizeof(uint32_t))))
             return rc;
         StageScope sc(h, IVFHNSW_STAGE_SCAN);
@@ -1358,6 +1361,10 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
                                       h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, nsplit, h->w_keys.as<uint64_t>(),
                                       h->w_counter.as<uint32_t>(), short_segments));
             h->last_scan_kernel = short_segments ? "scan_fused_kernel (short segments)" : "scan_fused_kernel";
+        } else if (pipe) {
+            HIP_TRY(launch_scan_pipe(h->stream, h->t, xq, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                                     h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, h->w_keys.as<uint64_t>()));
+            h->last_scan_kernel = "scan_pipe_kernel";
         } else {
             HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                                 h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),

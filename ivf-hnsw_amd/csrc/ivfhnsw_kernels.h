@@ -107,6 +107,10 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
                        uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0,
                        int seg_len_hint = 0); // expected codes per plan segment (0 = unknown): picks the scan form
 // table + scan in one persistent kernel, code book in registers (kernels_scan2.hip); k = 1, PQ16 / PQ8 at d = 128, 96
+// table + scan pipelined over queries, for list shards (kernels_scan3.hip)
+bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes);
+hipError_t launch_scan_pipe(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
+                            const PlanHdr *hdr, int max_seg, int nq, uint64_t *keys);
 bool scan_fused_supported(const IvfTables &t, bool short_segments);
 hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
                              const PlanHdr *hdr, int max_seg, int nq, int nsplit, uint64_t *keys, uint32_t *counter,

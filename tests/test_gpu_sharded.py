@@ -221,3 +221,49 @@ def test_sharded_searcher_step_with_opq(gpu, pkg, nsubc):
     g.sync()
     assert np.array_equal(ll.cpu().numpy(), ref_l)
     assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,d,M", [(2, 128, 16), (8, 128, 16), (3, 96, 16), (2, 128, 8), (5, 96, 8)])
+def test_sharded_pipelined_scan(gpu, pkg, world, d, M):
+    """Batches of >= 1024 queries on a list shard take scan_pipe_kernel (kernels_scan3.hip: table + scan software-pipelined
+    over queries, no table in HBM).  Plans longer than its first pass (2048 codes), queries with nothing on a shard,
+    and every code-book shape it is built for; merged keys must give the oracle's labels and distance bits."""
+    import torch
+    c = corpus(seed=300 + world, nc=128, d=d, M=M, n_base=40000, nq=1300)
+    nprobe, max_codes, ef = 12, 6000, 40
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef)
+    ref_d, ref_l, cid, cd, st = ox.search_batch(c["queries"], k=1)
+    nq = len(ref_l)
+    dev = torch.device("cuda", 0)
+    d_q = torch.from_numpy(c["queries"]).to(dev)
+    d_cid = torch.from_numpy(cid.astype(np.int32)).to(dev)
+    d_cd = torch.from_numpy(cd).to(dev)
+    # an owner table that leaves rank 0 few lists: many queries find nothing there (empty plans in the pipeline)
+    owner = (np.arange(128) % world).astype(np.int32)
+    if world > 2:
+        owner[owner == 0] = 1
+        owner[:3] = 0
+    shards, merged, total_codes = [], None, 0
+    for r in range(world):
+        g = gpu()
+        ids, codes, ncodes = _shard_arrays(c, r, world, owner)
+        g.upload_ivf(c["d"], c["code_size"], c["offsets"], ids, codes, ncodes, c["centroid_norms"], c["pq_centroids"],
+                     c["norm_table"], shard_rank=r, shard_world=world, list_owner=owner)
+        dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
+        ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+        kk = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+        g.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, d_coarse_ids=d_cid, d_coarse_dists=d_cd, d_out_keys=kk)
+        g.sync()
+        assert g.last_scan_kernel() == "scan_pipe_kernel"
+        total_codes += g.last_scan_counts()[0]
+        merged = kk if merged is None else torch.minimum(merged, kk)
+        shards.append((g, dd, ll))
+    assert total_codes == st.ncode
+    label = torch.full((nq, 1), -1, dtype=torch.int64, device=dev)
+    for g, dd, ll in shards:
+        g.resolve_keys_dev(nq, 1, merged, dd, ll)
+        g.sync()
+        label = torch.maximum(label, ll)
+    assert np.array_equal(label.cpu().numpy(), ref_l)
+    assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
