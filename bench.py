@@ -18,6 +18,11 @@ it owns for ALL queries, and the packed (distance, scan position) keys are MIN-a
 labels MAX-all-reduced.
   --scaling weak   (default): N x 10 k queries per step -- per-GPU work fixed (10 k walks, 1/N of N x the scan).
   --scaling strong           : 80 k queries per step at every N -- total work fixed.
+  --list-shards S  (default min(N, 4)): the N ranks as N / S replica groups of S list shards each; a group holds the
+                     whole corpus, serves its own S x 10 k batch, and its collectives stay inside the group.  S = N is
+                     one copy of the codes over the node; a 1B x PQ16 index is 26 GB of a GPU's 288, so 8 GPUs default to
+                     2 groups x 4 shards: list sharding replicates per-(query, shard) work, and beyond 4 shards a rank's
+                     step exceeds 1.15 x the one-GPU step (--list-shards 8 runs the single-copy layout).
 
 Prints ONE JSON line on rank 0.
 """
@@ -34,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+MAX_LIST_SHARDS = 4     # default list shards per replica group at N > 4 (--list-shards)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak (spec)
 METRIC = "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak"
 
@@ -134,6 +140,26 @@ def timed_steps(torch, step, barrier, n):
     return time.perf_counter() - t0
 
 
+def pmc_lds(workload):
+    """What actually bounds the ADC scan (profiles/, same PMC passes): the LDS array's busy share.  Every code costs
+    code_size random 4-byte gathers from the query's table; a 32-lane group of ds_read_b32 on 32 banks is a
+    balls-in-bins draw (~3 x the conflict-free rate), and the counters put the LDS array at >= 90 % busy."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "scan_traffic.json"))).get("workloads", {}).get(workload)
+        if e and "lds_idx_active_cycles" in e:
+            busy = e["lds_idx_active_cycles"] / (e["cus"] * e["launch_cycles"])
+            return {"busy_frac": round(busy, 3),
+                    "bank_conflict_share_of_lds_cycles": round(e["lds_bank_conflict_cycles"] / e["lds_idx_active_cycles"], 3),
+                    "lds_cycles_per_lds_instruction": round(e["lds_idx_active_cycles"] / e["lds_instructions"], 2),
+                    "effective_clock_ghz": round(e["launch_cycles"] / (e["launch_us"] * 1e3), 3),
+                    "source": e.get("lds_source", "profiles/scan_traffic.json"),
+                    "note": "SQ_LDS_IDX_ACTIVE / (CUs x GRBM_GUI_ACTIVE / 8): the scan is bound by LDS bank conflicts of its "
+                            "table gathers (DESIGN.md 3.1), which is why `frac` against HBM stops near 0.6"}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        pass
+    return None
+
+
 def scan_roofline(g, M, stage, traffic_gb):
     """`roofline` of the dominant kernel: algorithmic bytes (code_size + 1 per scored code) per launch
     over the kernel's average launch time (HIP events the library records around that launch on its stream)."""
@@ -171,6 +197,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--list-shards", type=int, default=0,
+                    help="N > 1: list shards per replica group (a divisor of N; default min(N, 4)).  The N ranks form N / S groups; a group holds the whole corpus in S list shards and "
+                         "serves its own batches, collectives stay inside the group (DESIGN.md 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
@@ -217,29 +246,47 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    C = Corpus(pkg, synth, args.workload, args.seed, dev, local_rank, rank, world, args.scale, args.partition, pkg_dist)
+    # replica groups x list shards: rank r is shard r % S of group r // S
+    # default: at most MAX_LIST_SHARDS shards per group -- beyond that the per-(query, shard) work that list sharding
+    # replicates (every shard builds the table of nearly every query for 1/S of its codes) costs a rank more than
+    # 15 % over the one-GPU step (measured); 8 GPUs run as 2 groups x 4 shards
+    S = args.list_shards if args.list_shards > 0 else (MAX_LIST_SHARDS if world % MAX_LIST_SHARDS == 0 else world)
+    S = min(S, world)
+    if world % S:
+        raise SystemExit("--list-shards %d does not divide --gpus %d" % (S, world))
+    R = world // S
+    srank, gidx = rank % S, rank // S
+    group = None
+    if world > 1 and S > 1 and R > 1:
+        for gi in range(R):  # every rank creates every group (torch.distributed's rule)
+            pg = dist.new_group(ranks=list(range(gi * S, (gi + 1) * S)))
+            if gi == gidx:
+                group = pg
+    C = Corpus(pkg, synth, args.workload, args.seed, dev, local_rank, srank, S, args.scale, args.partition, pkg_dist)
     g, d, M, nprobe, ef = C.g, C.d, C.M, C.nprobe, C.ef
     max_codes = C.max_codes
     if os.environ.get("IVFHNSW_BENCH_MAX_CODES"):   # experiment knob: longer / shorter scans per query
         max_codes = int(os.environ["IVFHNSW_BENCH_MAX_CODES"])
     grouping = C.grouping
+    # nq = the batch of THIS rank's group (every group its own queries); the job's batch is R of them
     if args.batch > 0:
         nq = args.batch
     elif args.scaling == "strong":
-        nq = STRONG_BATCH
+        nq = STRONG_BATCH // R
     else:
-        nq = C.nq * world * args.scale
-    queries = C.queries(nq, args.seed + 1)
+        nq = C.nq * S * args.scale
+    nq_job = nq * R
+    queries = C.queries(nq, args.seed + 1 + 7919 * gidx)
 
     # everything the timed region touches lives in HBM already
     g.set_stream(torch.cuda.current_stream().cuda_stream)
     d_q = torch.from_numpy(queries).to(dev)
     d_dist = torch.empty((nq, 1), dtype=torch.float32, device=dev)
     d_lab = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-    sharded = pkg_dist.ShardedSearcher(g, rank, world, nq, nprobe, dev) if world > 1 else None
+    sharded = pkg_dist.ShardedSearcher(g, srank, S, nq, nprobe, dev, group=group) if S > 1 else None
 
     def step():
-        if world == 1:
+        if S == 1:
             g.search_dev(nq, 1, d_q, d_dist, d_lab, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         else:
             # coarse walk for this rank's slice of the batch -> all-gather -> scan own shard for all queries ->
@@ -333,7 +380,7 @@ def main():
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        qps = nq * args.steps / elapsed
+        qps = nq_job * args.steps / elapsed
         single = world == 1 and args.scale == 1 and args.batch == 0 and args.scaling == "weak"
         traffic, walk_traffic = pmc_traffic(args.workload) if single else (None, None)
         walk_ms, walk_n = stage["coarse"]
@@ -342,7 +389,7 @@ def main():
         if world == 1:
             sharding = "replicas=1"
         else:
-            sharding = ("lists by owner table (%s partition), %s" % (args.partition,
+            sharding = ("%d replica group(s) x %d list shard(s) by owner table (%s partition), %s" % (R, S, args.partition,
                         "RCCL min-merge" if backend == "nccl" else "%s min-merge (single-GPU rehearsal)" % backend))
         out = {
             "metric": METRIC,
@@ -360,15 +407,16 @@ def main():
             "config": {
                 "workload": args.workload + ("" if args.scale == 1 else " x%d" % args.scale), "n_vectors": C.n_total,
                 "nc": C.nc, "d": d, "code_size": M, "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef,
-                "batch": nq, "k": 1, "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq, 1),
+                "batch": nq_job, "batch_per_group": nq, "k": 1, "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq_job, 1),
                 "sharding": sharding,
             },
             "value_is": "device-resident rate (queries and results in HBM, bench contract); SURVEY 8d's end-to-end "
                         "figure incl. H2D/D2H is host_pointer_queries_per_s",
             "sustained": {"steps": n_sus, "seconds": round(t_sus, 3),
-                          "queries_per_s": round(nq * n_sus / t_sus, 1) if t_sus > 0 else None,
+                          "queries_per_s": round(nq_job * n_sus / t_sus, 1) if t_sus > 0 else None,
                           "results_unchanged": sus_same},
             "roofline": scan_roofline(g, M, stage, traffic),
+            "roofline_lds": pmc_lds(args.workload) if single else None,
             # the kernel most of the step is spent in.  frac = its own HBM-side bytes (PMC) over its launch time, as a
             # fraction of the HBM peak; the reference's dist_calc accounting (dist_evals x 4d bytes, rows
             # the kernel's exact rejection filter mostly does not read) is reported separately by the cpu_baseline leg

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun -- 'bash profiles/collect.sh'): the default bench line, the same command under
-# rocprofv3 --kernel-trace --stats, and three PMC passes (each in its own run, counters only with kernel trace).
+# rocprofv3 --kernel-trace --stats, and four PMC passes (each in its own run, counters only with kernel trace).
 # Output under gpurun_out/prof/ (scratch); condense with profiles/summarize.py and commit the summary.
 set -e
 cd "$(dirname "$0")/.."
@@ -16,6 +16,7 @@ echo "[collect] stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$O/pmc_fetch" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_fetch.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$O/pmc_write" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_write.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d "$O/pmc_sq" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_sq.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_ACTIVE -d "$O/pmc_grbm" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_grbm.err"
 echo "[collect] pmc done"
 # keep the merge-back small: only the stats and counter tables travel
 find "$O" -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.json" ! -name "*.err" -delete

@@ -54,7 +54,7 @@ def _shard_best(c, q, cid, cd, max_codes, rank, world, pack_keys):
     return keys, labels
 
 
-def _worker(rank, world, port, ties, out_dir):
+def _worker(rank, world, port, ties, out_dir, shards=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -68,7 +68,19 @@ def _worker(rank, world, port, ties, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # replica groups x list shards (bench.py --list-shards): rank r is shard r % S of group r // S, every group
+    # serves its own queries and its collectives stay inside the group
+    S = shards or world
+    group, gidx, job_rank = None, rank // S, rank
+    if S != world:
+        for gi in range(world // S):
+            pg = dist.new_group(ranks=list(range(gi * S, (gi + 1) * S)))
+            if gi == gidx:
+                group = pg
+    rank, world = rank % S, S
     c = synth.make_corpus(seed=51, nc=96, d=64, M=8, n_base=6000, nq=24, efConstruction=60)
+    if gidx:
+        c["queries"] = np.ascontiguousarray(c["queries"][::-1] + np.float32(gidx))
     if ties:  # every code identical: all distances inside a list tie, across lists they differ by term1
         c["codes"] = np.zeros_like(c["codes"])
         c["norm_codes"] = np.zeros_like(c["norm_codes"])
@@ -83,22 +95,22 @@ def _worker(rank, world, port, ties, out_dir):
     cd_pad = torch.zeros((per * world, nprobe), dtype=torch.float32)
     cid_pad[rank * per:rank * per + (hi - lo)] = torch.from_numpy(cid[lo:hi].astype(np.int32))
     cd_pad[rank * per:rank * per + (hi - lo)] = torch.from_numpy(cd[lo:hi])
-    dist.all_gather_into_tensor(cid_pad, cid_pad[rank * per:(rank + 1) * per].clone())
-    dist.all_gather_into_tensor(cd_pad, cd_pad[rank * per:(rank + 1) * per].clone())
+    dist.all_gather_into_tensor(cid_pad, cid_pad[rank * per:(rank + 1) * per].clone(), group=group)
+    dist.all_gather_into_tensor(cd_pad, cd_pad[rank * per:(rank + 1) * per].clone(), group=group)
     g_cid = cid_pad.numpy()[:len(cid)].astype(np.uint32)
     g_cd = cd_pad.numpy()[:len(cid)]
     assert np.array_equal(g_cid, cid) and np.array_equal(g_cd, cd)
 
     keys, labels = _shard_best(c, c["queries"], g_cid, g_cd, max_codes, rank, world, D.pack_keys)
     tk = torch.from_numpy(keys.copy())
-    dist.all_reduce(tk, op=dist.ReduceOp.MIN)
+    dist.all_reduce(tk, op=dist.ReduceOp.MIN, group=group)
     merged = tk.numpy()
     mine = merged == keys
     tl = torch.from_numpy(np.where(mine, labels, -1))
-    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tl, op=dist.ReduceOp.MAX, group=group)
     dd, vv = D.unpack_keys(merged)
     ok = np.array_equal(tl.numpy(), ref_l[:, 0]) and np.array_equal(dd.view(np.uint32), ref_d[:, 0].view(np.uint32))
-    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "fail")), "w").write(
+    open(os.path.join(out_dir, "rank%d.%s" % (job_rank, "ok" if ok else "fail")), "w").write(
         "%s\n%s\n" % (tl.numpy().tolist(), ref_l[:, 0].tolist()))
     dist.destroy_process_group()
 
@@ -226,6 +238,16 @@ def test_shard_merge_equals_unsharded_oracle(tmp_path, world, ties):
     mp.spawn(_worker, args=(world, port, ties, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("rank%d.ok" % r)), open(tmp_path / ("rank%d.fail" % r)).read()
+
+
+def test_replica_groups_of_list_shards(tmp_path):
+    """4 ranks as 2 replica groups x 2 list shards (bench.py --list-shards 2): each group merges its own batch
+    inside its own process group and gets the unsharded oracle's result for ITS queries."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(4, port, False, str(tmp_path), 2), nprocs=4, join=True)
+    for r in range(4):
+        assert os.path.exists(os.path.join(str(tmp_path), "rank%d.ok" % r)), os.listdir(str(tmp_path))
 
 
 def test_key_packing_orders_like_distance_then_position():

@@ -4,6 +4,7 @@ corpus under the owner table bench.py --gpus N would use; the walk for its slice
 scan of ITS lists for all queries, then the label resolution.  Prints per-stage times -- the compute part of
 `bench.py --gpus N` per rank -- and, from the plan recomputed on the host, the codes every rank would score per step
 (max / mean: the load balance of the owner table).
+--world is the number of list shards of ONE replica group (bench.py --list-shards; 8 GPUs default to 2 groups x 4).
 usage: python tools/rank_emulation.py [--world 8] [--rank 0] [--scaling weak|strong] [--partition spatial|mod] [--workload W]"""
 import argparse
 import importlib

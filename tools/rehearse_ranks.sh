@@ -1,15 +1,17 @@
 #!/bin/bash
 # N ranks of bench.py on ONE GPU over gloo against the single-rank run of the same corpus and batch: labels and
 # distance bits must agree (N <= 5: the box allows six processes on its GPU and the launcher counts).
-# usage: bash tools/rehearse_ranks.sh <N> [workload] [extra bench args, e.g. --scaling strong]
+# usage: bash tools/rehearse_ranks.sh <N> [workload] [extra bench args, e.g. --scaling strong, --list-shards 2]
+# (with --list-shards S the comparison is rank 0's replica group: S shards, its own batch)
 set -e
 cd "$(dirname "$0")/.."
 N=${1:-4}; W=${2:-synthetic-100M-pq16-nc131072-nprobe32}; shift; shift || true
 B=$(python - "$W" "$N" "$@" <<'PY'
 import sys; sys.path.insert(0, '.')
 import bench
-w, n = sys.argv[1], int(sys.argv[2])
-print(bench.STRONG_BATCH if "strong" in sys.argv[3:] else bench.WORKLOADS[w][7] * n)
+w, n, rest = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
+s = int(rest[rest.index("--list-shards") + 1]) if "--list-shards" in rest else n  # rank 0's group: S shards, its own batch
+print(bench.STRONG_BATCH // (n // s) if "strong" in rest else bench.WORKLOADS[w][7] * s)
 PY
 )
 mkdir -p gpurun_out
