@@ -4,6 +4,7 @@
 # Output under gpurun_out/prof/ (scratch); condense with profiles/summarize.py and commit the summary.
 set -e
 cd "$(dirname "$0")/.."
+ROOT=$PWD
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
@@ -20,4 +21,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc GRBM_GUI_AC
 echo "[collect] pmc done"
 # keep the merge-back small: only the stats and counter tables travel
 find "$O" -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.json" ! -name "*.err" -delete
-find "$O" -name "*.csv" -exec ls -la {} +
+# ... condensed on the box: the raw counter tables (torch's data-generation kernels included) exceed the merge-back limit
+cd "$ROOT"
+python3 profiles/summarize.py "$O"/stats/*kernel_stats.csv "$O"/pmc_fetch/*counter_collection.csv "$O"/pmc_write/*counter_collection.csv \
+  "$O"/pmc_sq/*counter_collection.csv "$O"/pmc_grbm/*counter_collection.csv > "$O/summary.md"
+cp "$O"/stats/*kernel_stats.csv "$O/kernel_stats.csv"
+find "$O" -name "*counter_collection.csv" -delete
+ls -la "$O"
