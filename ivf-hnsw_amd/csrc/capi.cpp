@@ -124,6 +124,9 @@ struct ivfhnsw_gpu {
     bool e_opq = false, has_codebooks = false;
 
     // per-batch workspace
+    bool visited_zero = false;        // every byte of w_visited is zero (the walk's overflow bitmaps, kernels_hnsw.hip)
+    void *visited_zero_ptr = nullptr; // ... of this allocation
+    size_t visited_zero_bytes = 0;
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
         w_slen, w_counter, w_tail;
     // staging for the host-pointer entry point
@@ -826,6 +829,7 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         HIP_TRY(launch_coarse4(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
                                d_coarse_dists, h->w_visited.as<uint32_t>(), words, nwaves,
                                h->w_status.as<uint32_t>(), h->w_status.as<uint32_t>() + 1));
+        h->visited_zero = false; // that form's bitmaps stay as its last queries left them
     } else {
         // IVFHNSW_WALK_SLOTS caps the wavefronts the walk is launched with (experiments on the rounds a batch takes)
         static const size_t slot_cap = [] {
@@ -836,9 +840,14 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         const int nslots = (int)std::min<size_t>(std::min<size_t>(nq, slot_cap), (size_t)coarse_slots_for((int)efSearch));
         if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
             return rc;
+        if (h->w_visited.p != h->visited_zero_ptr || h->w_visited.bytes != h->visited_zero_bytes) {
+            h->visited_zero = false; // (re)allocated: contents unknown
+            h->visited_zero_ptr = h->w_visited.p;
+            h->visited_zero_bytes = h->w_visited.bytes;
+        }
         HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
                               d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
-                              h->w_status.as<uint32_t>() + 1));
+                              h->w_status.as<uint32_t>() + 1, h->w_visited.bytes, &h->visited_zero));
     }
     return IVFHNSW_OK;
 }

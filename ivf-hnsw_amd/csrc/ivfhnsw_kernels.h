@@ -82,6 +82,7 @@ struct GraphTables {
     // per node 32 rows of d floats (zero beyond the link count) and a 256-byte trailer with its links and link count;
     // NULL until ivfhnsw_gpu_prepare_latency builds it.
     const float *fat;
+    int visited_clean;    // walk (set by its launcher): the global visited bitmaps are zero on entry and left zero
     int skip_padding;     // walk: the filter skips the arithmetic of rows beyond the link count (A/B knob IVFHNSW_WALK_SKIPPAD)
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
     int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
@@ -135,7 +136,8 @@ hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, co
 // HNSW walk, one wavefront per query (hnswalg.cpp:48-109,227-234)
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query);
+                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query,
+                         size_t visited_bytes = 0, bool *visited_zero = nullptr); // in/out: the whole scratch is zero
 int coarse_slots_for(int ef);
 // one workgroup per query on the fat graph (small batches: the reference's one-query-per-call drivers)
 bool coarse_latency_supported(const GraphTables &g, int ef);

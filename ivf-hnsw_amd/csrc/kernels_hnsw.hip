@@ -243,7 +243,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     auto enc_id = [](uint32_t id, uint32_t c) { return CK ? (id << 7) | c : id; };
     auto dec_id = [](uint32_t e) { return CK ? e >> 7 : e; };
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
-    bool bitmap_dirty = true; // the bitmap must be wiped before its first use and after any query that used it
+    // The bitmap must be clean before a query uses it.  With the LDS set it is only the overflow store (rarely touched):
+    // the launcher hands it over zeroed ONCE (g.visited_clean) and a block that did touch it wipes it before it leaves,
+    // so launches do not start by clearing n / 8 bytes per resident wavefront (508 MB per launch at 993 127 nodes --
+    // it was ALL of the walk's WRITE_SIZE, 8 % of its traffic).
+    bool bitmap_dirty = !(LDSVIS && g.visited_clean);
 
     for (;;) {
         int q = 0;
@@ -820,6 +824,11 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
     }
+    if (LDSVIS && bitmap_dirty) { // leave the overflow store as it was found
+        uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+        for (size_t w = lane; w < vwords / 4; w += 64)
+            bm4[w] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if (STAMPS && stamp_out && lane == 0)
         for (int i = 0; i < 9; i++)
             atomicAdd(&stamp_out[i], st_acc[i]);
@@ -886,12 +895,14 @@ int coarse_slots_for(int ef)
     return 256 * 4 * waves_per_simd;
 }
 
-hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
+hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query)
+                         size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query,
+                         size_t visited_bytes, bool *visited_zero)
 {
     if (nq == 0)
         return hipSuccess;
+    GraphTables g = g_in;
     if (ef > 1024 || ef < 1 || nprobe > ef || g.maxM > 64 || g.n >= 0x80000000u || (visited_words_per_slot & 3))
         return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(next_query, 0, sizeof(uint32_t), s);
@@ -938,6 +949,20 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
                            sizeof(unsigned long long) +
                        (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
     const int fmode = g.nbrows ? (g.links_unique && tagw ? 3 : 2) : g.qrows ? 1 : 0;
+    // the global bitmaps: with the LDS set (tagw != 0) they are the overflow store, zero between launches -- cleared
+    // here once if the caller cannot vouch for them; the bitmap-only forms wipe per query and leave them used
+    g.visited_clean = 0;
+    if (tagw && visited_zero) {
+        if (!*visited_zero) {
+            e = hipMemsetAsync(visited_scratch, 0, visited_bytes, s);
+            if (e != hipSuccess)
+                return e;
+        }
+        g.visited_clean = 1;
+        *visited_zero = true;
+    } else if (visited_zero) {
+        *visited_zero = false;
+    }
 #define IVFHNSW_WALK_F(N, W, T, F)                                                                                    \
     hipLaunchKernelGGL((hnsw_walk_kernel<N, W, T, F>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,         \
                        coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
