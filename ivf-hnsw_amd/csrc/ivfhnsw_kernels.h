@@ -3,9 +3,36 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 namespace ivfhnsw_gpu_impl {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that drives several GPUs
+// (the bundled classes with IVFHNSW_SHARDS=N, one host thread per shard) must raise it on each of them, and the
+// bookkeeping of "already raised to ..." must be per device and safe against the shard threads.
+struct DynLdsState {
+    std::mutex m;
+    size_t raised[64] = {};
+};
+inline hipError_t raise_dyn_lds(const void *kern, size_t bytes, DynLdsState &st)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return e;
+    if (dev < 0 || dev >= 64)
+        return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    std::lock_guard<std::mutex> lk(st.m);
+    if (bytes > st.raised[dev]) {
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess)
+            return e;
+        st.raised[dev] = bytes;
+    }
+    return hipSuccess;
+}
+
 
 // One scored (sub)list of one query: the unit of the scan plan.
 // start  : index of the first code inside this shard's flat code array

@@ -590,13 +590,9 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
 #define IVFHNSW_LAT(N, J)                                                                                             \
     do {                                                                                                              \
         auto *kern = stamps ? hnsw_walk_lat_kernel<N, J, true> : hnsw_walk_lat_kernel<N, J, false>;                   \
-        static size_t attr = 0;                                                                                       \
-        if (shm > attr) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-            if (e != hipSuccess)                                                                                      \
-                return e;                                                                                             \
-            attr = shm;                                                                                               \
-        }                                                                                                             \
+        static DynLdsState attr[2];                                                                                   \
+        if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr[stamps ? 1 : 0]); e != hipSuccess)             \
+            return e;                                                                                                 \
         hipLaunchKernelGGL(kern, dim3(nq), dim3(LAT_THREADS), shm, s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, \
                            status, diag, zero_keys, zero_done);                                                                                   \
     } while (0)

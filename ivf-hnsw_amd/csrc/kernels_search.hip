@@ -867,13 +867,9 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
             return hipErrorInvalidValue;
         g_scan_kernel_name = "scan_k1_kernel (run-time code size)";
         auto *kern = scan_k1_kernel<0, 256, 2, 1, 256>;
-        static size_t attr_set = 0;
-        if (shm > attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            if (e != hipSuccess)
-                return e;
-            attr_set = shm;
-        }
+        static DynLdsState attr_set;
+        if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr_set); e != hipSuccess)
+            return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)nq * nsplit), dim3(256), shm, s, t.codes, t.norm_codes, luts, t.norm_table,
                            segs, lpos, hdr, max_seg, nsplit, reinterpret_cast<unsigned long long *>(keys), t.M);
         return hipGetLastError();

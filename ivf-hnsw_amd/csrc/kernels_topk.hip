@@ -413,13 +413,9 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
         if (t.M % 4 || shm > kScanDynLdsMax)
             return hipErrorInvalidValue;
         auto *kern = scan_topk_kernel<0>;
-        static size_t attr_set = 0;
-        if (shm > attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-            if (e != hipSuccess)
-                return e;
-            attr_set = shm;
-        }
+        static DynLdsState attr_set;
+        if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr_set); e != hipSuccess)
+            return e;
         hipLaunchKernelGGL(kern, grid, block, shm, s, t.codes, t.norm_codes, luts, t.norm_table, segs, lpos, hdr, max_seg, k,
                            k64, reinterpret_cast<unsigned long long *>(stream), stream_len, stream_cap, t.M);
         break;
