@@ -160,19 +160,24 @@ def pmc_lds(workload):
     return None
 
 
-def scan_roofline(g, M, stage, traffic_gb):
+def scan_roofline(g, M, stage, traffic_gb, steps):
     """`roofline` of the dominant kernel: algorithmic bytes (code_size + 1 per scored code) per launch
-    over the kernel's average launch time (HIP events the library records around that launch on its stream)."""
-    ncodes, _ = g.last_scan_counts()
+    over the kernel's average launch time (HIP events the library records around that launch on its stream).  A batch
+    of >= 8192 queries runs as two uneven parts on two streams (capi.cpp search_dev_split): two scan launches per step,
+    and the figures are per LAUNCH (what rocprofv3's average is, too): the step's codes and kernel time over both."""
+    ncodes_step, _ = g.last_scan_counts()
     scan_ms, scan_n = stage["scan"]
+    parts = max(1, int(round(scan_n / max(1, steps))))
+    ncodes = ncodes_step / parts
     avg_ms = scan_ms / max(1, scan_n)
     bpc = M + 1
     achieved = bpc * ncodes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     return {
+        "launches_per_step": parts,
         "bound": "hbm", "kernel": g.last_scan_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_gb,
         "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/scan_traffic.json)",
-        "algorithmic_gb_per_launch": round(bpc * ncodes / 1e9, 4), "bytes_per_code": bpc, "codes_per_launch": ncodes,
+        "algorithmic_gb_per_launch": round(bpc * ncodes / 1e9, 4), "bytes_per_code": bpc, "codes_per_launch": int(ncodes),
         "avg_launch_ms": round(avg_ms, 4),
     }
 
@@ -334,6 +339,28 @@ def main():
             g.search(queries, 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         host_qps = 3 * nq / (time.perf_counter() - t_h)
 
+    # The same batch as two uneven parts on two streams INSIDE one call (ivfhnsw_gpu_set_batch_split; reported beside
+    # `value`, never as it: `value` and `roofline` are measured with one launch per kernel).  The second part's walk
+    # fills the tail of the first part's, the first part's scan runs beside it.
+    split = None
+    if world == 1 and nq >= 8192:
+        g.set_batch_split(780)
+        sp_d, sp_l = torch.empty_like(d_dist), torch.empty_like(d_lab)
+        for _ in range(3):
+            g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        torch.cuda.synchronize()
+        n_sp = max(args.steps, n_sus // 4)
+        t_sp = time.perf_counter()
+        for _ in range(n_sp):
+            g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        torch.cuda.synchronize()
+        el_sp = time.perf_counter() - t_sp
+        g.set_batch_split(0)
+        split = {"first_part_permille": 780, "steps": n_sp, "queries_per_s": round(nq * n_sp / el_sp, 1),
+                 "ms_per_batch": round(el_sp / n_sp * 1e3, 4),
+                 "results_equal_to_one_part": bool(torch.equal(sp_l, d_lab)) and
+                 bool(torch.equal(sp_d.view(torch.int32), d_dist.view(torch.int32)))}
+
     # Serving form (reported beside `value`, never as it): --in-flight batches on as many streams, each on its own
     # view of the index (ivfhnsw_gpu_create_view: same tables, own workspace).  The walk is ALU-bound and ends in a
     # tail of partly filled SIMDs, the scan is HBM-bound: batches in flight overlap the two.
@@ -415,7 +442,7 @@ def main():
             "sustained": {"steps": n_sus, "seconds": round(t_sus, 3),
                           "queries_per_s": round(nq_job * n_sus / t_sus, 1) if t_sus > 0 else None,
                           "results_unchanged": sus_same},
-            "roofline": scan_roofline(g, M, stage, traffic),
+            "roofline": scan_roofline(g, M, stage, traffic, args.steps),
             "roofline_lds": pmc_lds(args.workload) if single else None,
             # the kernel most of the step is spent in.  frac = its own HBM-side bytes (PMC) over its launch time, as a
             # fraction of the HBM peak; the reference's dist_calc accounting (dist_evals x 4d bytes, rows
@@ -428,6 +455,7 @@ def main():
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
+            "split_batch": split,
         }
         if world > 1:
             out["shard_balance"] = {"codes_per_step_max_rank": float(nc_max.item()),
@@ -514,7 +542,7 @@ def main():
                 ent = {"workload": name, "value": round(s_nq * args.steps / t_s, 1), "unit": "queries/s",
                        "ms_per_step": round(t_s / args.steps * 1e3, 4), "nprobe": s_np, "max_codes": s_mc,
                        "efSearch": s_ef, "batch": s_nq,
-                       "roofline": scan_roofline(gg, CC.M, s_stage, pmc_traffic(name)[0]),
+                       "roofline": scan_roofline(gg, CC.M, s_stage, pmc_traffic(name)[0], args.steps),
                        "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in s_stage.items()}}
                 if not args.no_cpu_baseline:
                     from oracle import orc

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
-    "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
+    "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
     "ivfhnsw_gpu_device_count",
 )
 
@@ -108,6 +108,7 @@ def lib():
                                            C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_xty.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
+        L.ivfhnsw_gpu_set_batch_split.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
@@ -222,6 +223,10 @@ class GpuIndex:
     def prepare_latency(self):
         """Build the fat graph of the latency walk (one query per call; see ivfhnsw_gpu_prepare_latency)."""
         _check(lib().ivfhnsw_gpu_prepare_latency(self._h))
+
+    def set_batch_split(self, permille):
+        """Batches of >= 8192 queries as two uneven parts on two streams (ivfhnsw_gpu_set_batch_split); 0 = off."""
+        _check(lib().ivfhnsw_gpu_set_batch_split(self._h, int(permille)))
 
     # ---- search --------------------------------------------------------------------------------
     @staticmethod

@@ -124,6 +124,11 @@ struct ivfhnsw_gpu {
     bool e_opq = false, has_codebooks = false;
 
     // per-batch workspace
+    // one large batch as two uneven parts on two streams (ivfhnsw_gpu_search_dev): the second part runs on this view
+    ivfhnsw_gpu *split_view = nullptr;
+    hipEvent_t split_fork = nullptr, split_join = nullptr;
+    bool last_split = false;
+    int split_pm = 0; // permille of a large batch in its first part; 0 = one part (ivfhnsw_gpu_set_batch_split)
     bool visited_zero = false;        // every byte of w_visited is zero (the walk's overflow bitmaps, kernels_hnsw.hip)
     void *visited_zero_ptr = nullptr; // ... of this allocation
     size_t visited_zero_bytes = 0;
@@ -330,7 +335,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 7; }
+int ivfhnsw_gpu_abi_version(void) { return 8; }
 
 int ivfhnsw_gpu_device_count(int *count)
 {
@@ -342,6 +347,16 @@ int ivfhnsw_gpu_device_count(int *count)
         return fail(IVFHNSW_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
     *count = n;
     return IVFHNSW_OK;
+}
+
+static int split_permille_env()
+{
+    static const int v = [] {
+        const char *e = getenv("IVFHNSW_SPLIT");
+        const int x = (e && *e) ? atoi(e) : 0;
+        return (x > 0 && x < 1000) ? x : 0;
+    }();
+    return v;
 }
 
 int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
@@ -369,6 +384,7 @@ int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
         return fail(IVFHNSW_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
     }
     h->own_stream = true;
+    h->split_pm = split_permille_env();
     if (h->w_status.ensure(2 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
         ivfhnsw_gpu_destroy(h);
         return fail(IVFHNSW_ERR_HIP, "cannot allocate the device status word");
@@ -383,6 +399,15 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
         return IVFHNSW_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->split_view) {
+        ivfhnsw_gpu_destroy(h->split_view);
+        h->split_view = nullptr;
+        (void)hipSetDevice(h->device);
+    }
+    if (h->split_fork)
+        (void)hipEventDestroy(h->split_fork);
+    if (h->split_join)
+        (void)hipEventDestroy(h->split_join);
     for (auto &ev : h->pending) {
         (void)hipEventDestroy(ev.a);
         (void)hipEventDestroy(ev.b);
@@ -419,6 +444,7 @@ int ivfhnsw_gpu_create_view(ivfhnsw_gpu *parent, ivfhnsw_gpu **out)
     if ((rc = ivfhnsw_gpu_create(parent->device, &h)))
         return rc;
     h->is_view = true;
+    h->split_pm = 0;
     h->t = parent->t;
     h->has_ivf = parent->has_ivf;
     h->n_local = parent->n_local;
@@ -1193,21 +1219,105 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
 // to one slice.
 static const size_t kMaxBatchAll = 1 << 17;
 
+// One large batch as TWO uneven parts on two streams.  The walk's resident wavefronts pull queries from a counter, so a
+// launch ends with a tail of partly idle CUs (10 000 queries on 4096 slots: 2.44 "rounds"), and the scan can only start
+// when the last query has been walked.  Here the first ~78 % of the batch run on the handle's stream and the rest on an
+// internal view (own workspace and stream, same tables): the second part's walk moves into the slots the first part's
+// last round frees, and the first part's table + scan (LDS-bound) run beside it (HBM-bound).  Fork and join are events,
+// so the call keeps its contract: everything is ordered behind the caller's stream and complete when that stream gets
+// there.  Measured (tools/split_probe.py, 1B corpus, 10 k queries): 1.81 -> 1.67 ms per batch, the first part's scan at
+// 4.8 instead of 5.0 TB/s; three parts give no more, four lose.  Off by default (ivfhnsw_gpu_set_batch_split, or
+// IVFHNSW_SPLIT = permille of the batch in the first part): the second part's scan is a single round of workgroups and
+// drags the scan's average rate from 0.62 to 0.58 of the HBM peak while the step gains 8 %.  Not for sharded calls (their resolve step needs one plan), heap-order k > 1 (one
+// candidate stream), given coarse results (no walk to overlap) or batches below two rounds of the walk.
+static const size_t kSplitMinNq = 8192;
+
+int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille)
+{
+    if (!h)
+        return fail(IVFHNSW_ERR_INVALID, "null handle");
+    if (permille < 0 || permille >= 1000)
+        return fail(IVFHNSW_ERR_INVALID, "batch split %d outside 0..999 permille", permille);
+    if (h->is_view && permille)
+        return fail(IVFHNSW_ERR_INVALID, "a view cannot split its batches (it is what the second part runs on)");
+    h->split_pm = permille;
+    return IVFHNSW_OK;
+}
+
+static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const ivfhnsw_search_params *p,
+                            float *d_distances, int64_t *d_labels)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!h->split_view) {
+        if ((rc = ivfhnsw_gpu_create_view(h, &h->split_view)))
+            return rc;
+        HIP_TRY(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+    }
+    ivfhnsw_gpu *v = h->split_view;
+    // the view follows the handle's tables (uploads since its creation included)
+    v->t = h->t;
+    v->has_ivf = h->has_ivf;
+    v->n_local = h->n_local;
+    v->g = h->g;
+    v->has_group = h->has_group;
+    v->gr = h->gr;
+    v->has_graph = h->has_graph;
+    v->profiling = h->profiling;
+    // the second part: ~22 % of the batch, in whole "rounds" of the scan's resident workgroups (8 per CU x 256 CUs): its
+    // scan runs alone at the end of the step, and 2200 workgroups on 2048 slots would take two rounds for one
+    const size_t round_wgs = 2048;
+    size_t n2 = ((nq * (size_t)(1000 - h->split_pm) / 1000 + round_wgs / 2) / round_wgs) * round_wgs;
+    n2 = std::max(round_wgs, std::min(n2, nq / 2));
+    const size_t n1 = nq - n2;
+    const size_t d = (size_t)h->t.d;
+    HIP_TRY(hipEventRecord(h->split_fork, h->stream));
+    HIP_TRY(hipStreamWaitEvent(v->stream, h->split_fork, 0));
+    rc = search_dev_chunk(h, n1, k, d_queries, nullptr, nullptr, p, d_distances, d_labels, nullptr);
+    int rc2 = rc ? rc
+                 : search_dev_chunk(v, nq - n1, k, d_queries + n1 * d, nullptr, nullptr, p, d_distances + n1 * k,
+                                    d_labels + n1 * k, nullptr);
+    // whatever the second part flagged joins the handle's status word; the join itself, always (the fork was recorded)
+    (void)hipSetDevice(h->device);
+    if (!rc2)
+        (void)launch_status_merge(v->stream, v->w_status.as<uint32_t>(), h->w_status.as<uint32_t>());
+    HIP_TRY(hipEventRecord(h->split_join, v->stream));
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->split_join, 0));
+    h->last_split = rc2 == 0;
+    return rc2;
+}
+
+static int search_dev_part(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
+                           const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
+                           int64_t *d_labels, int64_t *d_out_keys)
+{
+    if (h)
+        h->last_split = false;
+    const bool split = h && p && !h->is_view && h->split_pm > 0 && nq >= kSplitMinNq && !d_coarse_ids &&
+                       !d_out_keys && !(p->heap_order && k > 1) && h->has_ivf && h->has_graph && p->nprobe > 0 && k > 0 &&
+                       k <= 1024 && d_queries && d_distances && d_labels;
+    if (split)
+        return search_dev_split(h, nq, k, d_queries, p, d_distances, d_labels);
+    return search_dev_chunk(h, nq, k, d_queries, d_coarse_ids, d_coarse_dists, p, d_distances, d_labels, d_out_keys);
+}
+
 int ivfhnsw_gpu_search_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const uint32_t *d_coarse_ids,
                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                            int64_t *d_labels, int64_t *d_out_keys)
 {
     const size_t kMaxBatch = (p && p->heap_order && k > 1) ? kMaxBatchAll / 8 : kMaxBatchAll;
     if (nq <= kMaxBatch || !h || !p)
-        return search_dev_chunk(h, nq, k, d_queries, d_coarse_ids, d_coarse_dists, p, d_distances, d_labels, d_out_keys);
+        return search_dev_part(h, nq, k, d_queries, d_coarse_ids, d_coarse_dists, p, d_distances, d_labels, d_out_keys);
     if (d_out_keys)
         return fail(IVFHNSW_ERR_INVALID, "sharded search (out_keys) is limited to %zu queries per call", kMaxBatch);
     const size_t d = (size_t)h->t.d;
     for (size_t q0 = 0; q0 < nq; q0 += kMaxBatch) {
         const size_t n = std::min(kMaxBatch, nq - q0);
-        int rc = search_dev_chunk(h, n, k, d_queries + q0 * d, d_coarse_ids ? d_coarse_ids + q0 * p->nprobe : nullptr,
-                                  d_coarse_dists ? d_coarse_dists + q0 * p->nprobe : nullptr, p, d_distances + q0 * k,
-                                  d_labels + q0 * k, nullptr);
+        int rc = search_dev_part(h, n, k, d_queries + q0 * d, d_coarse_ids ? d_coarse_ids + q0 * p->nprobe : nullptr,
+                                 d_coarse_dists ? d_coarse_dists + q0 * p->nprobe : nullptr, p, d_distances + q0 * k,
+                                 d_labels + q0 * k, nullptr);
         if (rc)
             return rc;
     }
@@ -1612,6 +1722,8 @@ int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled)
     if (rc)
         return rc;
     h->profiling = enabled != 0;
+    if (h->split_view)
+        h->split_view->profiling = h->profiling;
     return IVFHNSW_OK;
 }
 
@@ -1624,10 +1736,18 @@ int ivfhnsw_gpu_get_stage_ms(ivfhnsw_gpu *h, int stage, double *ms_total, uint64
         return fail(IVFHNSW_ERR_INVALID, "bad stage %d", stage);
     if ((rc = drain_events(h)))
         return rc;
+    double ms = h->stage_ms[stage];
+    uint64_t n = h->stage_n[stage];
+    if (h->split_view) { // the second part of split batches: its launches and their time join the handle's
+        if ((rc = drain_events(h->split_view)))
+            return rc;
+        ms += h->split_view->stage_ms[stage];
+        n += h->split_view->stage_n[stage];
+    }
     if (ms_total)
-        *ms_total = h->stage_ms[stage];
+        *ms_total = ms;
     if (launches)
-        *launches = h->stage_n[stage];
+        *launches = n;
     return IVFHNSW_OK;
 }
 
@@ -1642,6 +1762,8 @@ int ivfhnsw_gpu_reset_stage_ms(ivfhnsw_gpu *h)
         h->stage_ms[i] = 0;
         h->stage_n[i] = 0;
     }
+    if (h->split_view)
+        return ivfhnsw_gpu_reset_stage_ms(h->split_view);
     return IVFHNSW_OK;
 }
 
@@ -1656,6 +1778,14 @@ int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nse
                                    h->w_totals.as<unsigned long long>()));
         HIP_TRY(hipMemcpyAsync(out, h->w_totals.p, sizeof(out), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (h->last_split && h->split_view) {
+        uint64_t c2 = 0, s2 = 0;
+        if ((rc = ivfhnsw_gpu_last_scan_counts(h->split_view, &c2, &s2)))
+            return rc;
+        out[0] += c2;
+        out[1] += s2;
+        (void)hipSetDevice(h->device);
     }
     if (ncodes)
         *ncodes = out[0];

@@ -120,6 +120,8 @@ hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, 
 // tab[q][m][c] = <x_m, centroid[m][c]>  (IndexIVF_HNSW.cpp:262)
 // hdr (optional): queries whose plan is empty on this shard get no table
 hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq, const PlanHdr *hdr = nullptr);
+// *dst |= *src; *src = 0 (the status word of a split batch's second part joins the handle's)
+hipError_t launch_status_merge(hipStream_t s, uint32_t *src, uint32_t *dst);
 // probe order + max_codes rule (IndexIVF_HNSW.cpp:267-292); also resets keys[nq*k] to kKeyInit
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids,
                            const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs,

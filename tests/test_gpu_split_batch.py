@@ -1,0 +1,58 @@
+"""With ivfhnsw_gpu_set_batch_split, batches of >= 8192 queries run as two uneven parts on two streams inside
+ivfhnsw_gpu_search_dev (capi.cpp search_dev_split: the second part on an internal view, fork / join by events).  The call's contract must not move: labels,
+distance bits and the scanned-code count of the oracle for the WHOLE batch, results complete behind the caller's
+stream, the status word of the second part reported, host-pointer entry point included."""
+import numpy as np
+import pytest
+
+from conftest import corpus
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _upload(g, c):
+    g.upload_ivf(c["d"], c["code_size"], c["offsets"], c["ids"], c["codes"], c["norm_codes"], c["centroid_norms"],
+                 c["pq_centroids"], c["norm_table"], opq_A=c["opq_A"])
+    gr = c["graph"]
+    g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+    if c["nsubc"]:
+        g.upload_grouping(c["nsubc"], c["alphas"], c["nn_centroid_idxs"], c["subgroup_sizes"], c["inter_centroid_dists"])
+
+
+@pytest.mark.parametrize("grouping", [False, True])
+def test_split_batch_equals_oracle(gpu, grouping):
+    import torch
+    kw = dict(seed=71, nc=256, d=128, M=16, n_base=30000, nq=9000, efConstruction=60)
+    if grouping:
+        kw.update(nsubc=16, opq=True, seed=72)
+    c = corpus(**kw)
+    nprobe, max_codes, ef = 16, 2500, 40
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+    ref_d, ref_l, _, _, st = ox.search_batch(c["queries"], k=1)
+    g = gpu()
+    _upload(g, c)
+    g.set_batch_split(780)
+    dev = torch.device("cuda", 0)
+    nq = len(ref_l)
+    d_q = torch.from_numpy(c["queries"]).to(dev)
+    dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
+    ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):  # the second call reuses the internal view
+        dd.fill_(-1.0)
+        ll.fill_(-7)
+        g.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        # no explicit sync of the handle: reading through torch's stream must already see both parts
+        assert np.array_equal(ll.cpu().numpy(), ref_l)
+        assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+    assert g.last_scan_counts()[0] == st.ncode  # both parts' plans
+    # the host-pointer entry point takes the same path
+    hd, hl = g.search(c["queries"], 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+    assert np.array_equal(hl, ref_l) and np.array_equal(hd.view(np.uint32), ref_d.view(np.uint32))
+    # k > 1 (ascending) splits too
+    ref_d5, ref_l5, _, _, _ = ox.search_batch(c["queries"], k=5)
+    d5, l5 = g.search(c["queries"], 5, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+    o = np.argsort(ref_d5, axis=1, kind="stable")
+    assert np.array_equal(np.sort(d5, axis=1).view(np.uint32), np.take_along_axis(ref_d5, o, 1).view(np.uint32))

@@ -9,5 +9,5 @@ for v in "$@"; do
   echo "== $v"
   env $v python bench.py --no-cpu-baseline --in-flight 1 $W 2>/dev/null | python -c "
 import sys,json
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['stage_ms_per_step'])"
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['value'], j['stage_ms_per_step'], 'scan frac', j['roofline']['frac'], 'launch ms', j['roofline']['avg_launch_ms'])"
 done
