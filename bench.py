@@ -205,6 +205,7 @@ def main():
     ap.add_argument("--list-shards", type=int, default=0,
                     help="N > 1: list shards per replica group (a divisor of N; default min(N, 4)).  The N ranks form N / S groups; a group holds the whole corpus in S list shards and "
                          "serves its own batches, collectives stay inside the group (DESIGN.md 7)")
+    ap.add_argument("--no-split", action="store_true", help="skip the split_batch measurement (profiling runs: one launch shape per kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
@@ -343,7 +344,7 @@ def main():
     # `value`, never as it: `value` and `roofline` are measured with one launch per kernel).  The second part's walk
     # fills the tail of the first part's, the first part's scan runs beside it.
     split = None
-    if world == 1 and nq >= 8192:
+    if world == 1 and nq >= 8192 and not args.no_split:
         g.set_batch_split(780)
         sp_d, sp_l = torch.empty_like(d_dist), torch.empty_like(d_lab)
         for _ in range(3):

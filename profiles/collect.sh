@@ -10,7 +10,7 @@ O=$PWD/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
 timeout -k 10 500 python3 bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.err"
 echo "[collect] bench done"; tail -c 300 "$O/bench.json"
-B="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --sustain-s 0 --in-flight 1 $BENCH_ARGS"
+B="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-split --sustain-s 0 --in-flight 1 $BENCH_ARGS"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o run -- $B > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 echo "[collect] stats done"

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/probe
 rm -rf "$O"; mkdir -p "$O"
-B="python3 $PWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --in-flight 1 $BENCH_ARGS"
+B="python3 $PWD/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-split --in-flight 1 $BENCH_ARGS"
 cd /tmp
 i=0
 for set in "$@"; do
