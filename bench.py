@@ -449,7 +449,7 @@ def main():
             # fraction of the HBM peak; the reference's dist_calc accounting (dist_evals x 4d bytes, rows
             # the kernel's exact rejection filter mostly does not read) is reported separately by the cpu_baseline leg
             "roofline_walk": {
-                "bound": "latency / vector ALU (DESIGN.md 3.2), reported against HBM", "kernel": "hnsw_walk_kernel",
+                "bound": "hbm, random kilobyte pieces (DESIGN.md 3.2: at 993 127 nodes the walk runs near the rate HBM serves them; on cache-resident graphs its instruction stream binds)", "kernel": "hnsw_walk_kernel",
                 "avg_launch_ms": round(walk_avg_ms, 4), "traffic": walk_traffic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
