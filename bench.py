@@ -198,8 +198,9 @@ def pmc_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a timed region of ~0.4 s (200 steps of ~1.85 ms); 20 steps are 37 ms, shorter than the clocks take to settle
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--list-shards", type=int, default=0,
@@ -313,13 +314,24 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    g.set_profiling(True)
+    # HIP events over the timed region around the two kernels the rooflines are about (walk and scan): an event pair
+    # costs ~7 us of stream time, six pairs per step were 2.3 % of the step.  The other stages' times come from a few
+    # extra steps with every stage bracketed, after the region.
+    g.set_profiling(2)
     g.reset_stage_ms()
     elapsed = timed_steps(torch, step, barrier, args.steps)
     if rank == 0:
         log("[bench] timed region: %d steps in %.3fs" % (args.steps, elapsed))
     stage = g.stage_ms()
+    n_aux = 10
+    g.set_profiling(1)
+    g.reset_stage_ms()
+    timed_steps(torch, step, barrier, n_aux)
+    stage_all = g.stage_ms()
     g.set_profiling(False)
+    for name_, (ms_, n_) in stage_all.items():  # small stages: per step from the extra steps, scaled to the region
+        if name_ not in ("coarse", "scan"):
+            stage[name_] = (ms_ / n_aux * args.steps, int(round(n_ / n_aux * args.steps)))
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
     lab_gpu = d_lab.cpu().numpy()[:, 0].copy()
     dist_gpu = d_dist.cpu().numpy()[:, 0].copy()
@@ -454,6 +466,8 @@ def main():
                 "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
+            "stage_note": "coarse and scan: HIP events over the timed region; the small stages: %d extra steps with every "
+                          "stage bracketed (six event pairs per step cost 2.3 %% of it)" % n_aux,
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
             "split_batch": split,

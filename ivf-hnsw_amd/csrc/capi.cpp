@@ -147,7 +147,7 @@ struct ivfhnsw_gpu {
     bool walk_zeroed = false;
     bool last_stream = false; // the last search left a candidate stream (k > 1, heap_order)
 
-    bool profiling = false;
+    int profiling = 0; // 0 off, 1 every stage, 2 only the walk and the scan (an event pair costs ~7 us of stream time)
     std::vector<StageEvent> pending;
     std::vector<hipEvent_t> pool;
     double stage_ms[IVFHNSW_STAGE_COUNT] = {0};
@@ -190,7 +190,9 @@ struct StageScope {
     ivfhnsw_gpu *h;
     StageEvent ev{};
     bool on;
-    StageScope(ivfhnsw_gpu *h_, int stage) : h(h_), on(h_->profiling)
+    StageScope(ivfhnsw_gpu *h_, int stage)
+        : h(h_), on(h_->profiling == 1 ||
+                    (h_->profiling == 2 && (stage == IVFHNSW_STAGE_SCAN || stage == IVFHNSW_STAGE_COARSE)))
     {
         if (!on)
             return;
@@ -1721,7 +1723,7 @@ int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled)
     int rc = bind(h);
     if (rc)
         return rc;
-    h->profiling = enabled != 0;
+    h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     if (h->split_view)
         h->split_view->profiling = h->profiling;
     return IVFHNSW_OK;
