@@ -1427,22 +1427,6 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         h->last_stream = false;
         return IVFHNSW_OK;
     }
-    // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
-    {
-        StageScope sc(h, IVFHNSW_STAGE_PLAN);
-        if (h->has_group) {
-            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
-                return rc;
-            HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
-                                         p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
-                                         h->w_hdr.as<PlanHdr>(), max_seg, h->w_keys.as<uint64_t>(), (int)k,
-                                         h->w_qsd.as<float>()));
-        } else {
-            HIP_TRY(launch_plan_ivf(h->stream, h->t, cid, cd, (int)nq, nprobe, p->max_codes, h->w_segs.as<Seg>(),
-                                    h->w_lpos.as<uint32_t>(), h->w_hdr.as<PlanHdr>(), max_seg,
-                                    h->w_keys.as<uint64_t>(), (int)k));
-        }
-    }
     // a plan segment is a list (IVFADC) or a sub-group (Grouping): the mean length decides the scan form
     const uint64_t nseg_all = (uint64_t)h->t.nc * (h->has_group ? (uint64_t)h->g.nsubc : 1);
     const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
@@ -1457,14 +1441,45 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     // list shards: table and scan in one software-pipelined kernel, the table never leaves the chip (kernels_scan3.hip)
     const bool pipe = k == 1 && !fused && !h->has_group && !heap &&
                       scan_pipe_supported(h->t, max_seg, (int)nq, nsplit, h->n_local > 0);
+    // one GPU, IVFADC: plan and tables are independent of each other and go in ONE launch (kernels_search.hip
+    // plan_lut_kernel; IVFHNSW_PLAN_LUT=0 keeps them apart)
+    static const bool plan_lut_on = [] {
+        const char *e = getenv("IVFHNSW_PLAN_LUT");
+        return !(e && *e && atoi(e) == 0);
+    }();
+    const int ds = h->t.dsub;
+    const bool plan_lut = plan_lut_on && !h->has_group && !fused && !pipe && h->t.shard_world == 1 &&
+                          (ds == 4 || ds == 6 || ds == 8 || ds == 12 || ds == 16);
+    if (!fused && !pipe && (rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
+        return rc;
+    // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
+    if (plan_lut) {
+        StageScope sc(h, IVFHNSW_STAGE_LUT); // plan + tables: one kernel, accounted as the table stage
+        HIP_TRY(launch_plan_lut(h->stream, h->t, xq, cid, cd, (int)nq, nprobe, p->max_codes, h->w_segs.as<Seg>(),
+                                h->w_lpos.as<uint32_t>(), h->w_hdr.as<PlanHdr>(), max_seg, h->w_keys.as<uint64_t>(),
+                                (int)k, h->w_luts.as<float>()));
+    } else {
+        StageScope sc(h, IVFHNSW_STAGE_PLAN);
+        if (h->has_group) {
+            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
+                return rc;
+            HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
+                                         p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
+                                         h->w_hdr.as<PlanHdr>(), max_seg, h->w_keys.as<uint64_t>(), (int)k,
+                                         h->w_qsd.as<float>()));
+        } else {
+            HIP_TRY(launch_plan_ivf(h->stream, h->t, cid, cd, (int)nq, nprobe, p->max_codes, h->w_segs.as<Seg>(),
+                                    h->w_lpos.as<uint32_t>(), h->w_hdr.as<PlanHdr>(), max_seg,
+                                    h->w_keys.as<uint64_t>(), (int)k));
+        }
+    }
     // 4. table (IndexIVF_HNSW.cpp:262)
-    if (!fused && !pipe) {
-        if ((rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
-            return rc;
+    if (!fused && !pipe && !plan_lut) {
         StageScope sc(h, IVFHNSW_STAGE_LUT);
         HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq, h->w_hdr.as<PlanHdr>()));
     }
     // 5. scan (IndexIVF_HNSW.cpp:282-289)
+    bool scan_selected = false;
     if (heap) {
         // with out_keys (sharded search) the replay is the caller's: it merges the shards' candidate streams in scan
         // order first (ivfhnsw_gpu_last_stream_dev, ivfhnsw_gpu_replay_stream_dev)
@@ -1487,15 +1502,18 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
                                      h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, h->w_keys.as<uint64_t>()));
             h->last_scan_kernel = "scan_pipe_kernel";
         } else {
+            // k = 1 without out_keys: the scan writes distance and label itself where it can (no select launch)
+            const bool want_sel = k == 1 && !d_out_keys && !heap;
             HIP_TRY(launch_scan(h->stream, h->t, h->w_luts.as<float>(), h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                                 h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, (int)k, nsplit, h->w_keys.as<uint64_t>(),
                                 heap ? h->w_stream.as<uint64_t>() : nullptr, heap ? h->w_slen.as<uint32_t>() : nullptr,
-                                heap ? kHeapStreamCap : 0, seg_hint));
+                                heap ? kHeapStreamCap : 0, seg_hint, want_sel ? d_distances : nullptr,
+                                want_sel ? d_labels : nullptr, &scan_selected));
             h->last_scan_kernel = last_scan_kernel_name();
         }
     }
     // 6. select
-    {
+    if (!scan_selected) {
         StageScope sc(h, IVFHNSW_STAGE_SELECT);
         if (heap && !d_out_keys)
             HIP_TRY(launch_heap_replay(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,

@@ -126,6 +126,10 @@ hipError_t launch_status_merge(hipStream_t s, uint32_t *src, uint32_t *dst);
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids,
                            const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs,
                            uint32_t *lpos, PlanHdr *hdr, int max_seg, uint64_t *keys, int k);
+// plan_ivf + lut in one launch (one GPU; hipErrorInvalidValue for a dsub without an instantiation)
+hipError_t launch_plan_lut(hipStream_t s, const IvfTables &t, const float *xq, const uint32_t *coarse_ids,
+                           const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs, uint32_t *lpos,
+                           PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *luts);
 // Grouping: sub-centroid distances, pruning threshold, pass-2 plan (IndexIVF_HNSW_Grouping.cpp:222-353)
 hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
                                 const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
@@ -135,7 +139,10 @@ hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTa
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys,
                        uint64_t *stream = nullptr, uint32_t *stream_len = nullptr, uint32_t stream_cap = 0,
-                       int seg_len_hint = 0); // expected codes per plan segment (0 = unknown): picks the scan form
+                       int seg_len_hint = 0,
+                       // k = 1: let the scan resolve the winner's label itself where one workgroup sees the whole query;
+                       // *did_select tells whether it did (else launch_select has to run)
+                       float *sel_dist = nullptr, int64_t *sel_labels = nullptr, bool *did_select = nullptr); // expected codes per plan segment (0 = unknown): picks the scan form
 // table + scan in one persistent kernel, code book in registers (kernels_scan2.hip); k = 1, PQ16 / PQ8 at d = 128, 96
 // table + scan pipelined over queries, for list shards (kernels_scan3.hip)
 bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes);

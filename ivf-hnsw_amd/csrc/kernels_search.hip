@@ -98,13 +98,12 @@ hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, 
 constexpr int LUT_QB = 4;
 
 template <int DSUB>
-__global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, const float *__restrict__ cb,
-                                                  float *__restrict__ luts, int nq, int d, int M, int dsub_rt,
-                                                  const PlanHdr *__restrict__ hdr)
+__device__ __forceinline__ void lut_body(int bid, float *s_q, const float *__restrict__ xq, const float *__restrict__ cb,
+                                         float *__restrict__ luts, int nq, int d, int M, int dsub_rt,
+                                         const PlanHdr *__restrict__ hdr)
 {
-    extern __shared__ float s_q[]; // [LUT_QB][d]
     const int dsub = DSUB > 0 ? DSUB : dsub_rt;
-    const int q0 = blockIdx.x * LUT_QB;
+    const int q0 = bid * LUT_QB;
     const int nqb = min(LUT_QB, nq - q0);
     // a shard scores nothing for a query none of whose scanned lists it owns (16 % of the queries at 8 shards):
     // no table needed
@@ -143,6 +142,15 @@ __global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, 
             luts[((size_t)(q0 + qi) * M + m) * 256 + c] = r;
         }
     }
+}
+
+template <int DSUB>
+__global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, const float *__restrict__ cb,
+                                                  float *__restrict__ luts, int nq, int d, int M, int dsub_rt,
+                                                  const PlanHdr *__restrict__ hdr)
+{
+    extern __shared__ float s_q[]; // [LUT_QB][d]
+    lut_body<DSUB>((int)blockIdx.x, s_q, xq, cb, luts, nq, d, M, dsub_rt, hdr);
 }
 
 __global__ void status_merge_kernel(uint32_t *src, uint32_t *dst)
@@ -198,13 +206,13 @@ __device__ __forceinline__ unsigned long long wave_incl_scan_u64(unsigned long l
 
 // One wavefront per query, lanes over the probes (chunks of 64): list sizes in parallel, the max_codes prefix
 // rule by a wave scan -- list i is scored iff fewer than max_codes codes precede it in probe order.
-__global__ __launch_bounds__(256) void plan_ivf_kernel(IvfTables t, const uint32_t *__restrict__ cid,
-                                                       const float *__restrict__ cd, int nq, int nprobe,
-                                                       unsigned long long max_codes, Seg *__restrict__ segs,
-                                                       uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr,
-                                                       int max_seg, unsigned long long *__restrict__ keys, int k)
+__device__ __forceinline__ void plan_ivf_body(int bid, const IvfTables &t, const uint32_t *__restrict__ cid,
+                                              const float *__restrict__ cd, int nq, int nprobe,
+                                              unsigned long long max_codes, Seg *__restrict__ segs,
+                                              uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr, int max_seg,
+                                              unsigned long long *__restrict__ keys, int k)
 {
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = bid * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq)
         return;
@@ -254,6 +262,60 @@ __global__ __launch_bounds__(256) void plan_ivf_kernel(IvfTables t, const uint32
         h.total = nl;
         hdr[q] = h;
     }
+}
+
+__global__ __launch_bounds__(256) void plan_ivf_kernel(IvfTables t, const uint32_t *__restrict__ cid,
+                                                       const float *__restrict__ cd, int nq, int nprobe,
+                                                       unsigned long long max_codes, Seg *__restrict__ segs,
+                                                       uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr,
+                                                       int max_seg, unsigned long long *__restrict__ keys, int k)
+{
+    plan_ivf_body((int)blockIdx.x, t, cid, cd, nq, nprobe, max_codes, segs, lpos, hdr, max_seg, keys, k);
+}
+
+// Plan and tables of one batch in ONE launch (one GPU, IVFADC): they are independent of each other -- the plan needs the
+// coarse results, the tables the queries -- and the plan's 15 us of dependent list-size reads hide behind the tables'
+// 50 us of writes.  (On a list shard the table kernel skips queries the shard has nothing for, which it learns from the
+// plan: there the two stay separate launches.)  Blocks [0, plan_blocks) plan four queries each, the rest build tables.
+template <int DSUB>
+__global__ __launch_bounds__(256) void plan_lut_kernel(IvfTables t, const uint32_t *__restrict__ cid,
+                                                       const float *__restrict__ cd, int nq, int nprobe,
+                                                       unsigned long long max_codes, Seg *__restrict__ segs,
+                                                       uint32_t *__restrict__ lpos, PlanHdr *__restrict__ hdr,
+                                                       int max_seg, unsigned long long *__restrict__ keys, int k,
+                                                       int plan_blocks, const float *__restrict__ xq,
+                                                       float *__restrict__ luts)
+{
+    extern __shared__ float s_q[]; // [LUT_QB][d]
+    if ((int)blockIdx.x < plan_blocks)
+        plan_ivf_body((int)blockIdx.x, t, cid, cd, nq, nprobe, max_codes, segs, lpos, hdr, max_seg, keys, k);
+    else
+        lut_body<DSUB>((int)blockIdx.x - plan_blocks, s_q, xq, t.pq_centroids, luts, nq, t.d, t.M, t.dsub, nullptr);
+}
+
+hipError_t launch_plan_lut(hipStream_t s, const IvfTables &t, const float *xq, const uint32_t *coarse_ids,
+                           const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs, uint32_t *lpos,
+                           PlanHdr *hdr, int max_seg, uint64_t *keys, int k, float *luts)
+{
+    if (nq == 0)
+        return hipSuccess;
+    const int plan_blocks = (nq + 3) / 4, lut_blocks = (nq + LUT_QB - 1) / LUT_QB;
+    const dim3 grid(plan_blocks + lut_blocks), block(256);
+    const size_t shm = (size_t)LUT_QB * t.d * sizeof(float);
+    auto *k64 = reinterpret_cast<unsigned long long *>(keys);
+#define IVFHNSW_PLAN_LUT(DS)                                                                                          \
+    hipLaunchKernelGGL(plan_lut_kernel<DS>, grid, block, shm, s, t, coarse_ids, coarse_dists, nq, nprobe,             \
+                       (unsigned long long)max_codes, segs, lpos, hdr, max_seg, k64, k, plan_blocks, xq, luts)
+    switch (t.dsub) {
+    case 4: IVFHNSW_PLAN_LUT(4); break;
+    case 6: IVFHNSW_PLAN_LUT(6); break;
+    case 8: IVFHNSW_PLAN_LUT(8); break;
+    case 12: IVFHNSW_PLAN_LUT(12); break;
+    case 16: IVFHNSW_PLAN_LUT(16); break;
+    default: return hipErrorInvalidValue; // the caller keeps the two launches for other shapes
+    }
+#undef IVFHNSW_PLAN_LUT
+    return hipGetLastError();
 }
 
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids, const float *coarse_dists,
@@ -319,6 +381,39 @@ __device__ __forceinline__ float adc_sum_rep(const float *s_lut, const uint32_t 
     return sum;
 }
 
+// The winner's label resolved by the scan itself (k = 1, one workgroup per query, results wanted as distance + label):
+// select_kernel would re-read the key and the plan for 9 us and a launch.  ids == nullptr: keys only, as before.
+struct SelOut {
+    const uint32_t *ids;
+    float *dist;
+    long long *labels;
+};
+
+__device__ __forceinline__ void sel_write(const SelOut &so, int q, unsigned long long key, const Seg *sq, uint32_t nseg)
+{
+    float dv = FLT_MAX;
+    long long lb = -1;
+    if (key < kKeyInit) {
+        dv = orderable_f32((uint32_t)(key >> 32));
+        const uint32_t vpos = (uint32_t)key;
+        if (nseg != 0) {
+            uint32_t a = 0, b = nseg - 1; // last segment with seg.vpos <= vpos (segments are in scan order)
+            while (a < b) {
+                const uint32_t mid = (a + b + 1) >> 1;
+                if (sq[mid].vpos <= vpos)
+                    a = mid;
+                else
+                    b = mid - 1;
+            }
+            const Seg sg = sq[a];
+            if (vpos >= sg.vpos && vpos - sg.vpos < sg.len)
+                lb = (long long)so.ids[sg.start + (vpos - sg.vpos)];
+        }
+    }
+    so.dist[q] = dv;
+    so.labels[q] = lb;
+}
+
 template <int CS, int SEGCAP, int U, int REP, int THREADS>
 __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restrict__ codes,
                                                           const uint8_t *__restrict__ norm_codes,
@@ -327,7 +422,7 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                                                           const Seg *__restrict__ segs,
                                                           const uint32_t *__restrict__ lpos,
                                                           const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                          unsigned long long *__restrict__ keys, int cs_rt)
+                                                          unsigned long long *__restrict__ keys, int cs_rt, SelOut so)
 {
     // CS == 0: run-time code size cs_rt, table in dynamic LDS (code sizes without an instantiation of their own)
     __shared__ __attribute__((aligned(16))) float s_lut_fixed[(CS > 0 ? CS : 1) * 256 * REP];
@@ -343,8 +438,11 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
     const int q = blockIdx.x / nsplit;
     const int split = blockIdx.x - q * nsplit;
     const PlanHdr h = hdr[q];
-    if (h.total == 0)
+    if (h.total == 0) {
+        if (so.ids && tid == 0)
+            sel_write(so, q, kKeyInit, nullptr, 0);
         return;
+    }
     // this split's slice of the virtual code array, in multiples of the block width
     uint32_t per = (h.total + nsplit - 1) / nsplit;
     per = (per + (THREADS - 1)) & ~(uint32_t)(THREADS - 1);
@@ -484,10 +582,13 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
 #pragma unroll
         for (int i = 1; i < THREADS / 64; i++)
             b = s_red[i] < b ? s_red[i] : b;
-        if (nsplit == 1)
+        if (nsplit == 1) {
             keys[q] = b;
-        else if (b < kKeyInit)
+            if (so.ids)
+                sel_write(so, q, b, segs + (size_t)q * max_seg, h.nseg);
+        } else if (b < kKeyInit) {
             atomicMin(&keys[q], b);
+        }
     }
 }
 
@@ -604,7 +705,7 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
                                                              const Seg *__restrict__ segs,
                                                              const uint32_t *__restrict__ lpos,
                                                              const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                             unsigned long long *__restrict__ keys)
+                                                             unsigned long long *__restrict__ keys, SelOut so)
 {
     __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
     __shared__ float s_norm[256];
@@ -619,8 +720,11 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
     const int q = blockIdx.x / nsplit;
     const int split = blockIdx.x - q * nsplit;
     const PlanHdr h = hdr[q];
-    if (h.total == 0)
+    if (h.total == 0) {
+        if (so.ids && tid == 0)
+            sel_write(so, q, kKeyInit, nullptr, 0);
         return;
+    }
     uint32_t per = (h.total + nsplit - 1) / nsplit;
     per = (per + 255u) & ~255u;
     const uint32_t lo = min((uint32_t)split * per, h.total);
@@ -757,10 +861,13 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
 #pragma unroll
         for (int i = 1; i < 4; i++)
             m = s_red[i] < m ? s_red[i] : m;
-        if (nsplit == 1)
+        if (nsplit == 1) {
             keys[q] = m;
-        else if (m < kKeyInit)
+            if (so.ids)
+                sel_write(so, q, m, segs + (size_t)q * max_seg, h.nseg);
+        } else if (m < kKeyInit) {
             atomicMin(&keys[q], m);
+        }
     }
 }
 
@@ -782,8 +889,10 @@ static int scan_rep_choice()
 template <int CS>
 static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
                                  const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
-                                 uint64_t *keys, int seg_len_hint)
+                                 uint64_t *keys, int seg_len_hint, SelOut so, bool *did_select)
 {
+    if (nsplit != 1)
+        so.ids = nullptr; // several workgroups per query meet in an atomic: nobody knows the winner
     dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
     // short segments (Grouping sub-groups): a lane group per segment; IVFHNSW_SCAN_SHORT=0 keeps the position form
@@ -799,7 +908,9 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
     if (short_form >= 2 && seg_len_hint > 0 && seg_len_hint <= 48) {
         g_scan_kernel_name = "scan_k1_bitmap_kernel";
         hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table,
-                           segs, lpos, hdr, max_seg, nsplit, k64);
+                           segs, lpos, hdr, max_seg, nsplit, k64, so);
+        if (did_select)
+            *did_select = so.ids != nullptr;
         return hipGetLastError();
     }
     if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
@@ -820,7 +931,7 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
     }
 #define IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, UU)                                                                     \
     hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, UU, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
-                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, t.M)
+                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, t.M, so)
 #define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                 \
     do {                                                   \
         if (unroll == 2)                                   \
@@ -853,6 +964,8 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
     }
 #undef IVFHNSW_SCAN
 #undef IVFHNSW_SCAN_U
+    if (did_select)
+        *did_select = so.ids != nullptr;
     return hipGetLastError();
 }
 
@@ -862,8 +975,15 @@ hipError_t launch_scan_topk(hipStream_t s, const IvfTables &t, const float *luts
 
 hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs, const uint32_t *lpos,
                        const PlanHdr *hdr, int max_seg, int nq, int k, int nsplit, uint64_t *keys, uint64_t *stream,
-                       uint32_t *stream_len, uint32_t stream_cap, int seg_len_hint)
+                       uint32_t *stream_len, uint32_t stream_cap, int seg_len_hint, float *sel_dist, int64_t *sel_labels,
+                       bool *did_select)
 {
+    if (did_select)
+        *did_select = false;
+    SelOut so;
+    so.ids = (k == 1 && sel_dist && sel_labels) ? t.ids : nullptr;
+    so.dist = sel_dist;
+    so.labels = reinterpret_cast<long long *>(sel_labels);
     if (nq == 0)
         return hipSuccess;
     if (k != 1) {
@@ -871,10 +991,10 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
         return launch_scan_topk(s, t, luts, segs, lpos, hdr, max_seg, nq, k, keys, stream, stream_len, stream_cap);
     }
     switch (t.M) {
-    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
-    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
-    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
-    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint);
+    case 4: return launch_scan_cs<4>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, so, did_select);
+    case 8: return launch_scan_cs<8>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, so, did_select);
+    case 16: return launch_scan_cs<16>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, so, did_select);
+    case 32: return launch_scan_cs<32>(s, t, luts, segs, lpos, hdr, max_seg, nq, nsplit, keys, seg_len_hint, so, did_select);
     default: {
         // any other multiple of 4 (IndexIVF_HNSW.cpp:805): the run-time form, table in dynamic LDS
         const size_t shm = (size_t)t.M * 1024;
@@ -886,7 +1006,7 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
         if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr_set); e != hipSuccess)
             return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)nq * nsplit), dim3(256), shm, s, t.codes, t.norm_codes, luts, t.norm_table,
-                           segs, lpos, hdr, max_seg, nsplit, reinterpret_cast<unsigned long long *>(keys), t.M);
+                           segs, lpos, hdr, max_seg, nsplit, reinterpret_cast<unsigned long long *>(keys), t.M, SelOut{nullptr, nullptr, nullptr});
         return hipGetLastError();
     }
     }
