@@ -454,9 +454,14 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
     {
         const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * csz * 256);
         if constexpr (REP == 1) {
-            float4 *dst = reinterpret_cast<float4 *>(s_lut);
+            // global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16): the table never
+            // passes through VGPRs, and a ds_write_b128 costs the LDS pipe 13 cycles where the DMA's write costs 4
+            // -- the scan is bound by that pipe
+            const int lane = tid & 63;
             for (int i = tid; i < csz * 64; i += THREADS)
-                dst[i] = src[i];
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + i),
+                    (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(s_lut) + (i - lane)), 16, 0, 0);
         } else {
             constexpr int G = 32 / REP; // dwords of one copy inside a 32-dword bank row
             char *base = reinterpret_cast<char *>(s_lut);
@@ -733,9 +738,10 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
         return;
     {
         const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
-        float4 *dst = reinterpret_cast<float4 *>(s_lut);
-        for (int i = tid; i < CS * 64; i += 256)
-            dst[i] = src[i];
+        for (int i = tid; i < CS * 64; i += 256) // global -> LDS directly (see scan_k1_kernel)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + i),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(s_lut) + (i - lane)), 16, 0, 0);
         s_norm[tid] = norm_table[tid];
     }
     const Seg *sq = segs + (size_t)q * max_seg;
