@@ -1461,7 +1461,8 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     } else {
         StageScope sc(h, IVFHNSW_STAGE_PLAN);
         if (h->has_group) {
-            if (p->do_pruning && (rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
+            // per query: pass-1 values and sub-centroid distances of every (row, sub-group) the plan touches
+            if ((rc = h->w_qsd.ensure(nq * (size_t)max_seg * 2 * sizeof(float))))
                 return rc;
             HIP_TRY(launch_plan_grouping(h->stream, h->t, h->g, h->gr, xq, cid, cd, (int)nq, nprobe, p->max_codes,
                                          p->do_pruning, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),

@@ -9,6 +9,8 @@
 #include "ivfhnsw_kernels.h"
 #include "device_common.h"
 
+#include <stdlib.h>
+
 namespace ivfhnsw_gpu_impl {
 
 // scratch per query: qsd[max_seg] (pass-1 values, row-major [row][subc]) | qn[max_seg] (distances)
@@ -207,6 +209,262 @@ __global__ __launch_bounds__(64) void plan_grouping_kernel(IvfTables t, GroupTab
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same plan by FOUR wavefronts per query.  plan_grouping_kernel is one wavefront walking a long dependent chain:
+// ~26 probed groups x (4 gather passes of 16 rows, each a memory round trip, + the sequential threshold sum): ~0.5 ms
+// per query, 10 000 queries on the ~4096-8192 wavefronts that fit -- two "rounds" of one query latency, the second half
+// empty, at the SAME 1.3 ms whether the centroid table sits in the memory-side cache (100M shape) or in HBM (1B): it is
+// bound by that chain, not by bytes.  Which (probe, sub-group) distances a query needs is known from list sizes alone
+// (pass 1 runs until 2 x max_codes codes have been seen, Grouping.cpp:256-258; without pruning pass 2 runs until
+// max_codes), so the four wavefronts gather them for different probes at once into the per-query scratch (phase A); the
+// threshold is then summed by wavefront 0 in the reference's (probe, sub-group) order from that scratch (phase B), and
+// pass 2 -- bookkeeping over the probes in order -- runs on wavefront 0 as before, reading the distances (phase C).
+// Same arithmetic on the same operands in the same order wherever order matters: same bits.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_order()
+{
+    // LDS operations of one wavefront execute in order; this only stops hipcc from moving them across each other
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ unsigned long long incl_scan_u64(unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(v, off, 64);
+        if (lane >= off)
+            v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void plan_grouping4_kernel(IvfTables t, GroupTables g, GraphTables gr,
+                                                            const float *__restrict__ xq,
+                                                            const uint32_t *__restrict__ cid,
+                                                            const float *__restrict__ cd, int nq, int nprobe,
+                                                            unsigned long long max_codes, int do_pruning,
+                                                            Seg *__restrict__ segs, uint32_t *__restrict__ lpos,
+                                                            PlanHdr *__restrict__ hdr, int max_seg,
+                                                            unsigned long long *__restrict__ keys, int k,
+                                                            float *__restrict__ scratch)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_q[]; // query[d] | dist[4][64] | probe of row[nprobe]
+    __shared__ int s_p1, s_ra;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = blockIdx.x;
+    float *s_dist = s_q + t.d + wave * 64;
+    int *s_rowp = reinterpret_cast<int *>(s_q + t.d + 256);
+    const int nsubc = g.nsubc;
+    for (int j = tid; j < k; j += 256)
+        keys[(size_t)q * k + j] = kKeyInit;
+    for (int i = tid; i < t.d; i += 256)
+        s_q[i] = xq[(size_t)q * t.d + i];
+
+    float *qsd = scratch + (size_t)q * 2 * max_seg;
+    float *qnv = qsd + max_seg;
+    const uint32_t *qc = cid + (size_t)q * nprobe;
+    const float *qd = cd + (size_t)q * nprobe;
+
+    // ---- phase 0 (wavefront 0): the rows (non-empty probed groups, in probe order) and how many of them need distances
+    if (wave == 0) {
+        unsigned long long cum = 0;
+        int nrows = 0, p1 = -1, r2 = -1;
+        for (int base = 0; base < nprobe; base += 64) {
+            const int i = base + lane;
+            const uint32_t c = i < nprobe ? qc[i] : 0xffffffffu;
+            unsigned long long gs = 0;
+            if (c < t.nc)
+                gs = t.goff[c + 1] - t.goff[c];
+            const bool ne = gs != 0;
+            const unsigned long long m = __ballot(ne);
+            const unsigned long long incl = incl_scan_u64(gs, lane) + cum;
+            const int upto = nrows + __popcll(m & ((2ull << lane) - 1ull)); // rows up to and including this lane's
+            if (ne)
+                s_rowp[upto - 1] = i;
+            const unsigned long long h1 = __ballot(ne && incl >= 2 * max_codes);
+            const unsigned long long h2 = __ballot(ne && incl >= max_codes);
+            if (p1 < 0 && h1)
+                p1 = __shfl(upto, __ffsll((long long)h1) - 1, 64);
+            if (r2 < 0 && h2)
+                r2 = __shfl(upto, __ffsll((long long)h2) - 1, 64);
+            nrows += __popcll(m);
+            cum = __shfl(incl, 63, 64);
+        }
+        if (lane == 0) {
+            s_p1 = do_pruning ? (p1 >= 0 ? p1 : nrows) : 0;                      // Grouping.cpp:256-258
+            s_ra = do_pruning ? (p1 >= 0 ? p1 : nrows) : (r2 >= 0 ? r2 : nrows); // no pruning: what pass 2 will visit
+        }
+    }
+    __syncthreads();
+    const int p1_rows = s_p1, ra = s_ra;
+
+    // ---- phase A (all four wavefronts, rows dealt round robin): sub-centroid distances (and pass-1 values) to scratch
+    for (int r = wave; r < ra; r += 4) {
+        const int i = s_rowp[r];
+        const uint32_t c = qc[i];
+        const float alpha = g.alphas[c];
+        const float oma = __fsub_rn(1.0f, alpha);
+        const float term1 = __fmul_rn(oma, qd[i]);
+        for (int s0 = 0; s0 < nsubc; s0 += 64) {
+            const int subc = s0 + lane;
+            bool active = false;
+            float v = 0.f, qn = 0.f;
+            uint32_t nn = 0;
+            if (subc < nsubc && g.sub_sizes[(size_t)c * nsubc + subc] != 0) {
+                active = true;
+                nn = g.nn_idx[(size_t)c * nsubc + subc];
+            }
+            {
+                const unsigned long long am = __ballot(active);
+                const int na = __popcll(am);
+                for (int base = 0; base < na; base += 16) {
+                    const int rr = base + (lane >> 2);
+                    const int src = rr < na ? nth_set_bit(am, rr) : 0;
+                    const uint32_t nnq = (uint32_t)__shfl((int)nn, src, 64);
+                    float dq = 0.f;
+                    if (rr < na)
+                        dq = l2_ref_order_quad(gr.vectors + (size_t)nnq * t.d, s_q, t.d, lane & 3);
+                    if (rr < na && (lane & 3) == 0)
+                        s_dist[src] = dq;
+                }
+                wave_lds_order();
+                if (active)
+                    qn = s_dist[lane];
+                wave_lds_order();
+            }
+            if (active && do_pruning) {
+                const float a = __fmul_rn(oma, g.inter_dists[(size_t)c * nsubc + subc]);
+                const float b = __fsub_rn(a, qn);
+                v = __fsub_rn(term1, __fmul_rn(alpha, b)); // Grouping.cpp:251-252
+            }
+            if (subc < nsubc) {
+                if (do_pruning)
+                    qsd[(size_t)r * nsubc + subc] = v; // value-initialised 0.0 where inactive (:228)
+                qnv[(size_t)r * nsubc + subc] = qn;
+            }
+        }
+    }
+    __syncthreads(); // the scratch of this query is complete (workgroup-scope fence)
+    if (wave != 0)
+        return;
+
+    // ---- phase B (wavefront 0): the threshold, summed in (probe, sub-group) order (Grouping.cpp:253, 261)
+    float threshold = 0.0f;
+    if (do_pruning) {
+        unsigned long long nsubgroups = 0;
+        for (int r = 0; r < p1_rows; r++) {
+            const uint32_t c = qc[s_rowp[r]];
+            for (int s0 = 0; s0 < nsubc; s0 += 64) {
+                const int subc = s0 + lane;
+                const bool active = subc < nsubc && g.sub_sizes[(size_t)c * nsubc + subc] != 0;
+                const float v = active ? qsd[(size_t)r * nsubc + subc] : 0.f;
+                unsigned long long m = __ballot(active);
+                nsubgroups += __popcll(m);
+                while (m) {
+                    const int j = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    threshold = __fadd_rn(threshold, __shfl(v, j, 64));
+                }
+            }
+        }
+        threshold = __fdiv_rn(threshold, (float)nsubgroups); // :261, 0/0 = NaN when nothing was seen
+    }
+
+    // ---- phase C (wavefront 0): pass 2 (Grouping.cpp:283-353), distances from the scratch for the rows phase A covered
+    unsigned long long ncode = 0; // codes scored so far == scan position of the next one
+    uint32_t ns = 0, nl = 0;
+    int row = 0;
+    Seg *sq = segs + (size_t)q * max_seg;
+    uint32_t *lq = lpos + (size_t)q * max_seg;
+    for (int i = 0; i < nprobe; i++) {
+        const uint32_t c = qc[i];
+        if (c >= t.nc)
+            continue;
+        const unsigned long long gs = t.goff[c + 1] - t.goff[c];
+        if (gs == 0)
+            continue;
+        const float alpha = g.alphas[c];
+        const float oma = __fsub_rn(1.0f, alpha);
+        const float term1 = __fmul_rn(oma, __fsub_rn(qd[i], t.centroid_norms[c]));
+        const uint32_t lo_c = t.loff[c];
+        const bool owned = lo_c != kNotOwned;
+        const bool have = row < ra; // this row's distances are in the scratch
+        uint32_t list_off = 0;      // codes of this list before the current chunk of sub-groups
+        for (int s0 = 0; s0 < nsubc; s0 += 64) {
+            const int subc = s0 + lane;
+            uint32_t sz = 0;
+            bool scanned = false;
+            float cterm = 0.f;
+            if (subc < nsubc)
+                sz = g.sub_sizes[(size_t)c * nsubc + subc];
+            if (sz != 0) {
+                float qs = 0.0f;
+                if (do_pruning && row < p1_rows)
+                    qs = qsd[(size_t)row * nsubc + subc];
+                scanned = !do_pruning || qs < threshold; // :308
+            }
+            float qn2 = 0.f;
+            const bool need = scanned && !have;
+            if (scanned && have)
+                qn2 = qnv[(size_t)row * nsubc + subc];
+            {
+                const uint32_t nn = scanned ? g.nn_idx[(size_t)c * nsubc + subc] : 0u;
+                const unsigned long long am = __ballot(need);
+                const int na = __popcll(am);
+                if (na) { // rows beyond what the sizes promised (pass 2 ran further than pass 1): evaluated here
+                    for (int base = 0; base < na; base += 16) {
+                        const int rr = base + (lane >> 2);
+                        const int src = rr < na ? nth_set_bit(am, rr) : 0;
+                        const uint32_t nnq = (uint32_t)__shfl((int)nn, src, 64);
+                        float dq = 0.f;
+                        if (rr < na)
+                            dq = l2_ref_order_quad(gr.vectors + (size_t)nnq * t.d, s_q, t.d, lane & 3);
+                        if (rr < na && (lane & 3) == 0)
+                            s_dist[src] = dq;
+                    }
+                    wave_lds_order();
+                    if (need)
+                        qn2 = s_dist[lane];
+                    wave_lds_order();
+                }
+                if (scanned) {
+                    const float term2 = __fmul_rn(alpha, __fsub_rn(qn2, t.centroid_norms[nn])); // :318
+                    cterm = __fadd_rn(term1, term2);
+                }
+            }
+            const uint32_t in_sz = wave_incl_scan(sz, lane);
+            const uint32_t in_sc = wave_incl_scan(scanned ? sz : 0u, lane);
+            const unsigned long long m = __ballot(scanned);
+            const uint32_t rank_sc = __popcll(m & ((1ull << lane) - 1ull));
+            if (scanned && owned) {
+                Seg sg;
+                sg.start = lo_c + list_off + (in_sz - sz);
+                sg.len = sz;
+                sg.vpos = (uint32_t)ncode + (in_sc - sz);
+                sg.cterm = cterm;
+                sq[ns + rank_sc] = sg;
+                lq[ns + rank_sc] = nl + (in_sc - sz);
+            }
+            const uint32_t tot_sz = __shfl(in_sz, 63, 64), tot_sc = __shfl(in_sc, 63, 64);
+            list_off += tot_sz;
+            ncode += tot_sc;
+            if (owned) {
+                ns += (uint32_t)__popcll(m);
+                nl += tot_sc;
+            }
+        }
+        if (ncode >= max_codes)
+            break;
+        row++;
+    }
+    if (lane == 0) {
+        PlanHdr h;
+        h.nseg = ns;
+        h.total = nl;
+        hdr[q] = h;
+    }
+}
+
 hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTables &g, const GraphTables &gr,
                                 const float *xq, const uint32_t *coarse_ids, const float *coarse_dists, int nq,
                                 int nprobe, uint64_t max_codes, int do_pruning, Seg *segs, uint32_t *lpos,
@@ -214,9 +472,20 @@ hipError_t launch_plan_grouping(hipStream_t s, const IvfTables &t, const GroupTa
 {
     if (nq == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), (t.d + 64) * sizeof(float), s, t, g, gr, xq, coarse_ids,
-                       coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr, max_seg,
-                       reinterpret_cast<unsigned long long *>(keys), k, scratch);
+    // IVFHNSW_PLAN_GROUP4=0: the one-wavefront-per-query form (A/B runs)
+    static const bool four = [] {
+        const char *e = getenv("IVFHNSW_PLAN_GROUP4");
+        return !(e && *e && atoi(e) == 0);
+    }();
+    if (four)
+        hipLaunchKernelGGL(plan_grouping4_kernel, dim3(nq), dim3(256),
+                           (size_t)(t.d + 256) * sizeof(float) + (size_t)nprobe * sizeof(int), s, t, g, gr, xq, coarse_ids,
+                           coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr, max_seg,
+                           reinterpret_cast<unsigned long long *>(keys), k, scratch);
+    else
+        hipLaunchKernelGGL(plan_grouping_kernel, dim3(nq), dim3(64), (t.d + 64) * sizeof(float), s, t, g, gr, xq,
+                           coarse_ids, coarse_dists, nq, nprobe, (unsigned long long)max_codes, do_pruning, segs, lpos, hdr,
+                           max_seg, reinterpret_cast<unsigned long long *>(keys), k, scratch);
     return hipGetLastError();
 }
 

@@ -66,6 +66,7 @@ def test_every_knob_setting_reproduces_the_default_path():
                 {"IVFHNSW_SCAN_SHORT": "1"},         # ... through the lane-group-per-segment form (default: the bitmap form)
                 {"IVFHNSW_TAIL": "0"},               # small batches through the four separate launches
                 {"IVFHNSW_SCAN_FUSED": "1"},         # table + scan fused (kernels_scan2.hip), both segment forms
+                {"IVFHNSW_PLAN_GROUP4": "0"},        # Grouping plan by one wavefront per query (default: four)
                 {"IVFHNSW_PLAN_LUT": "0"},           # plan and tables as two launches (default: one, plan_lut_kernel)
                 {"IVFHNSW_SCAN_PIPE": "1"},          # table + scan pipelined over queries (kernels_scan3.hip), one shard too
                 {"IVFHNSW_SCAN_U": "2"}, {"IVFHNSW_SCAN_REP": "2"}):
