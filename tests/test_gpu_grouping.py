@@ -73,3 +73,27 @@ def test_grouping_requires_quantizer(gpu, pkg):
         g.search(c["queries"][:2], 1, 4, 100, coarse_ids=np.zeros((2, 4), np.uint32),
                  coarse_dists=np.zeros((2, 4), np.float32))
     assert e.value.code == pkg.ERR_STATE
+
+
+BIG_CASES = [
+    # larger batches (>= 1024 queries), more probes than a wavefront has lanes, nsubc > 64:
+    # corpus, nprobe, max_codes, efSearch
+    (dict(seed=46, nc=256, d=128, M=16, n_base=30000, nq=1500, nsubc=16), 16, 800, 40),
+    (dict(seed=47, nc=128, d=96, M=16, n_base=20000, nq=1100, nsubc=80, opq=True, efConstruction=120), 24, 2500, 64),
+    (dict(seed=48, nc=256, d=128, M=8, n_base=20000, nq=1300, nsubc=8), 200, 10 ** 9, 220),  # more probes than a wavefront
+]
+
+
+@pytest.mark.parametrize("do_pruning", [False, True])
+@pytest.mark.parametrize("kw,nprobe,max_codes,ef", BIG_CASES)
+def test_grouping_large_batches_match_oracle(gpu, kw, nprobe, max_codes, ef, do_pruning):
+    """Same contract as above on batches of more than a thousand queries, with up to 200 probes per query."""
+    c = corpus(**kw)
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=do_pruning)
+    ref_d, ref_l, _, _, st = ox.search_batch(c["queries"], k=1)
+    g = _gpu_index(gpu, c)
+    dist, lab = g.search(c["queries"], 1, nprobe, max_codes, efSearch=ef, do_pruning=do_pruning)
+    assert np.array_equal(lab, ref_l)
+    assert np.array_equal(dist.view(np.uint32), ref_d.view(np.uint32))
+    assert g.last_scan_counts()[0] == st.ncode
