@@ -314,8 +314,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events over the timed region around the two kernels the rooflines are about (walk and scan): an event pair
-    # costs ~7 us of stream time, six pairs per step were 2.3 % of the step.  The other stages' times come from a few
+    # HIP events over the timed region around the kernel the roofline is about (the scan): an event pair costs ~7 us of
+    # stream time, six pairs per step were 2.3 % of the step.  The other stages' times (the walk's too) come from a few
     # extra steps with every stage bracketed, after the region.
     g.set_profiling(2)
     g.reset_stage_ms()
@@ -330,7 +330,7 @@ def main():
     stage_all = g.stage_ms()
     g.set_profiling(False)
     for name_, (ms_, n_) in stage_all.items():  # small stages: per step from the extra steps, scaled to the region
-        if name_ not in ("coarse", "scan"):
+        if name_ != "scan":
             stage[name_] = (ms_ / n_aux * args.steps, int(round(n_ / n_aux * args.steps)))
     ncodes, nsegs = g.last_scan_counts()  # per step, this shard
     lab_gpu = d_lab.cpu().numpy()[:, 0].copy()
@@ -466,7 +466,7 @@ def main():
                 "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
-            "stage_note": "coarse and scan: HIP events over the timed region; the small stages: %d extra steps with every "
+            "stage_note": "scan: HIP events over the timed region; the other stages (the walk too): %d extra steps with every "
                           "stage bracketed (six event pairs per step cost 2.3 %% of it)" % n_aux,
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,

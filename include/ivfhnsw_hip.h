@@ -276,8 +276,8 @@ enum ivfhnsw_stage {
     IVFHNSW_STAGE_COUNT = 6
 };
 /* With profiling on, every search brackets each stage with hipEvents on the launch stream: enabled = 1 every stage,
- * 2 only the coarse walk and the scan (an event pair costs about 7 us of stream time; six of them are 2 % of a
- * 10 k-query step), 0 off. */
+ * 2 only the scan, the kernel the roofline is about (an event pair costs about 7 us of stream time; six of them are
+ * 2 % of a 10 k-query step), 0 off. */
 int ivfhnsw_gpu_set_profiling(ivfhnsw_gpu *h, int enabled);
 /* Accumulated since the last reset: milliseconds and number of launches of one stage. */
 int ivfhnsw_gpu_get_stage_ms(ivfhnsw_gpu *h, int stage, double *ms_total, uint64_t *launches);

@@ -353,7 +353,7 @@ class GpuIndex:
 
     # ---- measurement ---------------------------------------------------------------------------
     def set_profiling(self, on):
-        """True / 1: hipEvents around every stage; 2: only around the coarse walk and the scan; False / 0: off."""
+        """True / 1: hipEvents around every stage; 2: only around the scan; False / 0: off."""
         _check(lib().ivfhnsw_gpu_set_profiling(self._h, 2 if on == 2 else (1 if on else 0)))
 
     def reset_stage_ms(self):

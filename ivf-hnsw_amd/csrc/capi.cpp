@@ -147,7 +147,7 @@ struct ivfhnsw_gpu {
     bool walk_zeroed = false;
     bool last_stream = false; // the last search left a candidate stream (k > 1, heap_order)
 
-    int profiling = 0; // 0 off, 1 every stage, 2 only the walk and the scan (an event pair costs ~7 us of stream time)
+    int profiling = 0; // 0 off, 1 every stage, 2 only the scan (an event pair costs ~7 us of stream time)
     std::vector<StageEvent> pending;
     std::vector<hipEvent_t> pool;
     double stage_ms[IVFHNSW_STAGE_COUNT] = {0};
@@ -192,7 +192,7 @@ struct StageScope {
     bool on;
     StageScope(ivfhnsw_gpu *h_, int stage)
         : h(h_), on(h_->profiling == 1 ||
-                    (h_->profiling == 2 && (stage == IVFHNSW_STAGE_SCAN || stage == IVFHNSW_STAGE_COARSE)))
+                    (h_->profiling == 2 && stage == IVFHNSW_STAGE_SCAN))
     {
         if (!on)
             return;
