@@ -18,11 +18,18 @@ it owns for ALL queries, and the packed (distance, scan position) keys are MIN-a
 labels MAX-all-reduced.
   --scaling weak   (default): N x 10 k queries per step -- per-GPU work fixed (10 k walks, 1/N of N x the scan).
   --scaling strong           : 80 k queries per step at every N -- total work fixed.
-  --list-shards S  (default min(N, 4)): the N ranks as N / S replica groups of S list shards each; a group holds the
-                     whole corpus, serves its own S x 10 k batch, and its collectives stay inside the group.  S = N is
-                     one copy of the codes over the node; a 1B x PQ16 index is 26 GB of a GPU's 288, so 8 GPUs default to
-                     2 groups x 4 shards: list sharding replicates per-(query, shard) work, and beyond 4 shards a rank's
-                     step exceeds 1.15 x the one-GPU step (--list-shards 8 runs the single-copy layout).
+  --list-shards S  (default N): the N ranks as N / S replica groups of S list shards each; a group holds the whole
+                     corpus, serves its own S x 10 k batch, and its collectives stay inside the group.  S = N -- ONE copy
+                     of the 1B-vector code array sharded across the N GPUs, the layout BASELINE.json's north_star names --
+                     is what `value` reports.  The same line carries `replica_groups`: the same job as 2 groups x N/2
+                     shards (a 1B x PQ16 index is 26 GB of a GPU's 288, and list sharding replicates per-(query, shard)
+                     work: DESIGN.md 7), measured in the same run on the same ranks.
+
+`python bench.py --gpus N` from a bare shell (WORLD_SIZE unset, N > 1) starts the N ranks itself: the parent -- before it
+imports torch, loads the library or touches the GPU in any way -- runs `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, which
+prints rank 0's JSON line on the inherited stdout, and exits with its code.  Under an external launcher (WORLD_SIZE set)
+the process is a rank and runs as before.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,6 +37,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,7 +48,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-MAX_LIST_SHARDS = 4     # default list shards per replica group at N > 4 (--list-shards)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak (spec)
 METRIC = "queries/sec @ Recall@1, SIFT1B PQ16 nprobe=32; ADC scan HBM GB/s vs peak"
 
@@ -95,14 +103,22 @@ class Corpus:
             self.opq_A = synth.random_rotation(np.random.default_rng(seed + 4), d)
             self.vectors = synth.rotated_vectors(tb["centroids"], self.opq_A)
         t_tab = time.time() - t0
+        self.code_seed = seed + 7
+        self.pkg, self.pkg_dist, self.local_rank, self.partition, self.t_tab = pkg, pkg_dist, local_rank, partition, t_tab
+        self.g, self.owner = None, None
+        self.upload(rank, world, verbose=rank == 0)
+
+    def upload(self, rank, world, verbose=False):
+        """This rank's shard of the corpus as `rank` of `world` list shards on the device (a new handle; the previous
+        one, if any, stays open and is the caller's to close: another layout of the same tables and graph)."""
+        tb, d, M = self.tb, self.d, self.M
         self.owner = None
         if world > 1:
             sizes = np.diff(tb["offsets"].astype(np.int64))
-            load = pkg_dist.expected_list_load(sizes, self.counts, self.links)
-            self.owner = pkg_dist.partition_lists(tb["centroids"], sizes, world, partition, load=load)
-        self.code_seed = seed + 7
+            load = self.pkg_dist.expected_list_load(sizes, self.counts, self.links)
+            self.owner = self.pkg_dist.partition_lists(tb["centroids"], sizes, world, self.partition, load=load)
         t0 = time.time()
-        self.g = g = pkg.GpuIndex(local_rank)
+        self.g = g = self.pkg.GpuIndex(self.local_rank)
         g.upload_ivf_synthetic(d, M, tb["offsets"], self.centroid_norms, tb["pq_centroids"], tb["norm_table"],
                                self.code_seed, opq_A=self.opq_A, shard_rank=rank, shard_world=world,
                                list_owner=self.owner)
@@ -110,9 +126,10 @@ class Corpus:
         if self.grouping:
             g.upload_grouping(64, self.gt["alphas"], self.gt["nn_centroid_idxs"], self.gt["subgroup_sizes"],
                               self.gt["inter_centroid_dists"])
-        if rank == 0:
-            log("[bench] %s: tables + graph %.1fs (avg degree %.1f), on device %.1fs, %.2f GB held"
-                % (name, t_tab, self.counts.mean(), time.time() - t0, g.memory_bytes() / 1e9))
+        if verbose:
+            log("[bench] %s: tables + graph %.1fs (avg degree %.1f), shard %d/%d on device %.1fs, %.2f GB held"
+                % (self.name, self.t_tab, self.counts.mean(), rank, world, time.time() - t0, g.memory_bytes() / 1e9))
+        return g
 
     def queries(self, nq, seed):
         rng = np.random.default_rng(seed)
@@ -122,7 +139,9 @@ class Corpus:
 
     def oracle(self, synth, orc):
         """The CPU port over a full host copy of the device's byte stream (the cpu_baseline / parity leg only)."""
-        ids_h, codes_h, ncodes_h = synth.synthetic_codes(self.code_seed, self.tb["offsets"], self.M)
+        if getattr(self, "_host", None) is None:   # one host copy, shared by the two oracle builds
+            self._host = synth.synthetic_codes(self.code_seed, self.tb["offsets"], self.M)
+        ids_h, codes_h, ncodes_h = self._host
         graph = orc.Hnsw.from_arrays(self.counts, self.links, self.vectors, 16, 0)
         kw = {}
         if self.grouping:
@@ -195,6 +214,22 @@ def pmc_traffic(workload):
     return None, None
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` from a bare shell: start N fresh rank processes and relay rank 0's line and the exit code.
+    Runs BEFORE this process has imported torch, loaded libivfhnsw_hip.so or made any GPU call -- a process that has
+    initialised the GPU must never be replaced or forked into ranks -- and the ranks are children, not an exec."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL / dmabuf IPC on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without WORLD_SIZE: starting the ranks: %s" % (n, " ".join(cmd[1:9])))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,8 +239,11 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("IVFHNSW_BENCH_WORKLOAD", DEFAULT_WORKLOAD))
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--list-shards", type=int, default=0,
-                    help="N > 1: list shards per replica group (a divisor of N; default min(N, 4)).  The N ranks form N / S groups; a group holds the whole corpus in S list shards and "
+                    help="N > 1: list shards per replica group (a divisor of N; default N = one copy of the codes over the "
+                         "N GPUs).  The N ranks form N / S groups; a group holds the whole corpus in S list shards and "
                          "serves its own batches, collectives stay inside the group (DESIGN.md 7)")
+    ap.add_argument("--no-replica-layout", action="store_true",
+                    help="N > 1: skip the extra `replica_groups` measurement (2 groups x N/2 shards on the same ranks)")
     ap.add_argument("--no-split", action="store_true", help="skip the split_batch measurement (profiling runs: one launch shape per kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
@@ -221,6 +259,9 @@ def main():
     ap.add_argument("--sustain-s", type=float, default=1.2, help="length of the extra sustained measurement, seconds")
     ap.add_argument("--dump", default=None, help="write rank 0's labels/distances of the last step to this .npz")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # oracle threads must not spin inside a CPU quota
     import torch
@@ -244,6 +285,9 @@ def main():
     backend = os.environ.get("IVFHNSW_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:  # counting devices does not initialise the GPU
+        raise SystemExit("--gpus %d over RCCL needs %d GPUs, this box shows %d (one-GPU rehearsal: IVFHNSW_BENCH_BACKEND=gloo)"
+                         % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -253,22 +297,28 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # replica groups x list shards: rank r is shard r % S of group r // S
-    # default: at most MAX_LIST_SHARDS shards per group -- beyond that the per-(query, shard) work that list sharding
-    # replicates (every shard builds the table of nearly every query for 1/S of its codes) costs a rank more than
-    # 15 % over the one-GPU step (measured); 8 GPUs run as 2 groups x 4 shards
-    S = args.list_shards if args.list_shards > 0 else (MAX_LIST_SHARDS if world % MAX_LIST_SHARDS == 0 else world)
+    # replica groups x list shards: rank r is shard r % S of group r // S.  Default S = N: one copy of the code arrays
+    # sharded over the N GPUs (north_star); the 2 x N/2 layout is measured beside it (`replica_groups`).
+    S = args.list_shards if args.list_shards > 0 else world
     S = min(S, world)
     if world % S:
         raise SystemExit("--list-shards %d does not divide --gpus %d" % (S, world))
     R = world // S
+    S2 = world // 2 if (world > 1 and world % 2 == 0 and S == world and not args.no_replica_layout) else 0
+
+    def make_group(shards):
+        """This rank's process group in the layout of `shards` list shards per replica group (None = the world)."""
+        mine = None
+        if world > 1 and 1 < shards < world:
+            for gi in range(world // shards):  # every rank creates every group (torch.distributed's rule)
+                pg = dist.new_group(ranks=list(range(gi * shards, (gi + 1) * shards)))
+                if gi == rank // shards:
+                    mine = pg
+        return mine
+
     srank, gidx = rank % S, rank // S
-    group = None
-    if world > 1 and S > 1 and R > 1:
-        for gi in range(R):  # every rank creates every group (torch.distributed's rule)
-            pg = dist.new_group(ranks=list(range(gi * S, (gi + 1) * S)))
-            if gi == gidx:
-                group = pg
+    group = make_group(S)
+    group2 = make_group(S2) if S2 else None
     C = Corpus(pkg, synth, args.workload, args.seed, dev, local_rank, srank, S, args.scale, args.partition, pkg_dist)
     g, d, M, nprobe, ef = C.g, C.d, C.M, C.nprobe, C.ef
     max_codes = C.max_codes
@@ -341,6 +391,42 @@ def main():
     n_sus = max(args.steps, int(math.ceil(args.sustain_s / max(1e-6, elapsed / args.steps))))
     t_sus = timed_steps(torch, step, barrier, n_sus) if args.sustain_s > 0 else 0.0
     sus_same = bool((d_lab.cpu().numpy()[:, 0] == lab_gpu).all())
+
+    # N > 1: the same job as 2 replica groups x N/2 list shards, on the same ranks in the same run (`replica_groups`,
+    # reported beside `value`, never as it): another upload of the same tables, graph and byte stream
+    replica = None
+    if S2:
+        s2rank, g2idx = rank % S2, rank // S2
+        g2 = C.upload(s2rank, S2, verbose=rank == 0)
+        g2.set_stream(torch.cuda.current_stream().cuda_stream)
+        nq2 = (STRONG_BATCH // 2) if args.scaling == "strong" else C.nq * S2 * args.scale
+        if args.batch > 0:
+            nq2 = max(1, args.batch * S2 // S)
+        q2 = torch.from_numpy(C.queries(nq2, args.seed + 1 + 7919 * g2idx)).to(dev)
+        dd2 = torch.empty((nq2, 1), dtype=torch.float32, device=dev)
+        ll2 = torch.empty((nq2, 1), dtype=torch.int64, device=dev)
+        sh2 = pkg_dist.ShardedSearcher(g2, s2rank, S2, nq2, nprobe, dev, group=group2) if S2 > 1 else None
+
+        def step2():
+            if S2 == 1:
+                g2.search_dev(nq2, 1, q2, dd2, ll2, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+            else:
+                sh2.step(q2, dd2, ll2, max_codes, ef, do_pruning=grouping)
+
+        for _ in range(3 + args.warmup):
+            step2()
+        barrier()
+        el2 = timed_steps(torch, step2, barrier, args.steps)
+        red2 = torch.tensor([el2], dtype=torch.float64, device=dev if backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(red2, op=dist.ReduceOp.MAX)
+        el2 = float(red2[0].item())
+        replica = {"groups": 2, "list_shards_per_group": S2, "batch_per_group": nq2, "batch": 2 * nq2,
+                   "value": round(2 * nq2 * args.steps / el2, 1), "unit": "queries/s",
+                   "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                   "note": "every group holds the whole corpus in %d list shard(s) and serves its own batch; collectives "
+                           "stay inside the group" % S2}
+        g2.close()
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # the host-pointer entry point of the C ABI (queries in, distances and labels out over PCIe): SURVEY 8d's
     # end-to-end figure; never `value` (the contract wants inputs resident in HBM), reported beside it
@@ -429,7 +515,9 @@ def main():
         if world == 1:
             sharding = "replicas=1"
         else:
-            sharding = ("%d replica group(s) x %d list shard(s) by owner table (%s partition), %s" % (R, S, args.partition,
+            sharding = ("%s: %d replica group(s) x %d list shard(s) by owner table (%s partition), %s" % (
+                        "ONE copy of the code arrays sharded list-wise over the %d GPUs" % world if R == 1 else "replica groups",
+                        R, S, args.partition,
                         "RCCL min-merge" if backend == "nccl" else "%s min-merge (single-GPU rehearsal)" % backend))
         out = {
             "metric": METRIC,
@@ -448,7 +536,7 @@ def main():
                 "workload": args.workload + ("" if args.scale == 1 else " x%d" % args.scale), "n_vectors": C.n_total,
                 "nc": C.nc, "d": d, "code_size": M, "nprobe": nprobe, "max_codes": max_codes, "efSearch": ef,
                 "batch": nq_job, "batch_per_group": nq, "k": 1, "coarse": "device HNSW walk", "codes_scored_per_query": round(ncodes_all / nq_job, 1),
-                "sharding": sharding,
+                "sharding": sharding, "replica_groups": R, "list_shards": S,
             },
             "value_is": "device-resident rate (queries and results in HBM, bench contract); SURVEY 8d's end-to-end "
                         "figure incl. H2D/D2H is host_pointer_queries_per_s",
@@ -472,6 +560,8 @@ def main():
             "pipelined": pipe,
             "split_batch": split,
         }
+        if replica is not None:
+            out["replica_groups"] = replica
         if world > 1:
             out["shard_balance"] = {"codes_per_step_max_rank": float(nc_max.item()),
                                     "codes_per_step_mean_rank": round(ncodes_all / world, 1),
@@ -526,6 +616,28 @@ def main():
             out["parity"] = {"queries_checked": nq, "labels_equal": same_l, "distances_bit_equal": same_d}
             if same_l != nq or same_d != nq:
                 log("[bench] PARITY FAILURE: %d/%d labels, %d/%d distances" % (same_l, nq, same_d, nq))
+            # north_star's tolerance clause, measured on this batch: the same port with the float associations g++ 11.4
+            # emits for the reference's loops under the reference's own flags (-Ofast -march=native, CMakeLists.txt:22;
+            # oracle/liborc_ofast.so, tests/test_oracle_float_order.py) -- how many top-1 ids would differ from a
+            # reference binary built today
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("orc_ofast", os.path.join(ROOT, "oracle", "orc.py"))
+                orc_of = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(orc_of)
+                orc_of.LIB_PATH = os.path.join(ROOT, "oracle", "liborc_ofast.so")
+                if os.path.exists(orc_of.LIB_PATH):
+                    oy = C.oracle(synth, orc_of)
+                    oy.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+                    fd, fl, _, _, _ = oy.search_batch(queries, 1, ncores)
+                    out["float_order"] = {
+                        "what": "top-1 of the CPU port in source order vs the same port in the association of the "
+                                "reference's -Ofast -march=native build (fma in the L2 loop, tree lane sum, pairwise ADC)",
+                        "queries": nq, "top1_ids_differ": int((fl[:, 0] != rl_all[:, 0]).sum()),
+                        "distances_differ_in_bits": int((fd[:, 0].view(np.uint32) != rd_all[:, 0].view(np.uint32)).sum()),
+                        "north_star_tolerance": "Recall@1 within +-0.1 % for float ties"}
+            except Exception as e:  # the measuring stick must never fail the bench
+                log("[bench] float_order leg skipped: %r" % (e,))
 
         # secondary results in the same line: the 1B corpus at configs[2]'s operating point, and configs[1]
         if single and args.workload == DEFAULT_WORKLOAD and not args.no_secondary:

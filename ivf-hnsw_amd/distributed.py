@@ -176,12 +176,24 @@ def merge_streams(streams, lens, cap):
 
 
 class ShardedSearcher:
-    """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller."""
+    """Drives one GpuIndex shard per rank.  All tensors are torch CUDA tensors owned by the caller.
 
-    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1, force_collectives=False):
+    Stream contract: the collectives run on torch's current stream, the shard's kernels on the handle's stream, and
+    nothing else orders the two -- so the constructor BINDS the handle to torch's current stream of `device`
+    (ivfhnsw_gpu_set_stream) and step() checks that it is still the current one.  A caller that wants another stream
+    enters `torch.cuda.stream(s)` before constructing the searcher and around every step."""
+
+    def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1, force_collectives=False,
+                 stream_cap=None):
         import torch
         self.g, self.rank, self.world, self.nq, self.nprobe, self.group = gpu_index, rank, world, nq, nprobe, group
         self.k = k
+        self.device = torch.device(device)
+        self.stream_cap = stream_cap  # tests: a smaller candidate-stream capacity than the library's (overflow path)
+        self.bound_stream = None
+        if self.device.type == "cuda":
+            self.bound_stream = torch.cuda.current_stream(self.device).cuda_stream
+            gpu_index.set_stream(self.bound_stream)
         # run every collective even in a world of one (a single-rank RCCL group accepts them all): lets a one-GPU box
         # execute the very calls the 8-GPU node makes (tests/test_gpu_rccl_single_rank.py)
         self.collectives = world > 1 or force_collectives
@@ -216,6 +228,9 @@ class ShardedSearcher:
         import torch
         import torch.distributed as dist
         g, k, nq = self.g, self.k, self.nq
+        if self.bound_stream is not None and torch.cuda.current_stream(self.device).cuda_stream != self.bound_stream:
+            raise RuntimeError("ShardedSearcher.step on another torch stream than the one its handle is bound to: the "
+                               "collectives would not be ordered behind the shard's kernels")
         self.coarse(d_q, efSearch)
         heap = heap_order and k > 1
         g.search_dev(nq, k, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
@@ -229,12 +244,17 @@ class ShardedSearcher:
         else:
             lens = torch.empty((nq,), dtype=torch.int32, device=d_q.device)
             cap = g.last_stream_dev(nq, d_len=lens)
+            if self.stream_cap is not None:
+                cap = min(cap, self.stream_cap)
             g.sync()  # torch reads below: order them after the handle's stream
             lmax = lens.max().to(torch.int64).view(1)
-            if int(lmax.item()) > cap:
-                raise RuntimeError("candidate stream of a query exceeded %d entries: use ascending order" % cap)
+            # MAX over the shards BEFORE the overflow test: every rank must take the same branch, or the ranks that do
+            # not overflow would wait in the all-gathers below for one that has left the step
             if self.collectives:
                 _all_reduce(lmax, dist.ReduceOp.MAX, self.group)
+            if int(lmax.item()) > cap:
+                raise RuntimeError("candidate stream of a query exceeded %d entries on some shard: use ascending "
+                                   "order" % cap)
             L = max(1, int(lmax.item()))
             mine = torch.empty((nq, L), dtype=torch.int64, device=d_q.device)
             g.last_stream_dev(nq, L, d_keys=mine)
@@ -245,7 +265,8 @@ class ShardedSearcher:
             else:
                 streams, all_lens = mine.unsqueeze(0), lens.unsqueeze(0)
             merged, total = merge_streams(streams, all_lens, cap)
-            torch.cuda.current_stream().synchronize()
+            if self.device.type == "cuda":
+                torch.cuda.current_stream(self.device).synchronize()
             g.replay_stream_dev(nq, k, merged, total, merged.shape[1], self.keys)
         g.resolve_keys_dev(nq, k, self.keys, d_dist, d_lab)
         if self.collectives:

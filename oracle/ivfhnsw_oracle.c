@@ -28,6 +28,7 @@
 /* hnswlib/hnswalg.cpp:326-357 (fstdistfunc) and utils.cpp:22-52 (fvec_L2sqr), AVX branch.
  * One __m256 accumulator = 8 lanes; each loop iteration consumes 16 floats as two 8-wide
  * sub/mul/add steps; TmpRes[0]+...+TmpRes[7] is summed left to right. */
+#ifndef ORC_OFAST_ORDER
 float orc_l2sqr(const float *x, const float *y, size_t d)
 {
     /* one 8-wide vector accumulator == the 8 lanes; element-wise sub, mul, add, each rounded
@@ -53,6 +54,30 @@ float orc_l2sqr(const float *x, const float *y, size_t d)
     res = res + acc[7];
     return res;
 }
+#else
+/* The association g++ 11.4 ACTUALLY emits for that source under the reference's own flags (CMakeLists.txt:22,
+ * -Ofast -march=native on an FMA machine), read from the assembly of the same loop shape:
+ *   loop, per 16 floats:  t = d1*d1;  u = fma(d0, d0, t);  sum = sum + u     (vmulps, vfmadd132ps, vaddps)
+ *   horizontal sum:       ((s5+s6) + (s3+s4)) + ((s7+s1) + (s0+s2))
+ * Built as liborc_ofast.so (make -C oracle ofast) to MEASURE how often the two orders disagree on a top-1 id; the
+ * source order above stays the contract. */
+float orc_l2sqr(const float *x, const float *y, size_t d)
+{
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t nblk = d >> 4;
+    for (size_t b = 0; b < nblk; b++)
+        for (int l = 0; l < 8; l++) {
+            float d0 = x[b * 16 + l] - y[b * 16 + l];
+            float d1 = x[b * 16 + 8 + l] - y[b * 16 + 8 + l];
+            float t = d1 * d1;
+            float u = fmaf(d0, d0, t);
+            s[l] = s[l] + u;
+        }
+    float a = (s[5] + s[6]) + (s[3] + s[4]);
+    float c = (s[7] + s[1]) + (s[0] + s[2]);
+    return a + c;
+}
+#endif
 
 /* faiss spec (utils.cpp, SSE build per CMakeLists.txt.faiss:24): fvec_inner_product keeps one
  * __m128 of 4 partial sums, consumes 4 floats per step, loads the tail zero padded, then
@@ -546,6 +571,7 @@ orc_hnsw *orc_hnsw_load(const char *path_info, const char *path_data, const char
  * ============================================================================================= */
 
 /* IndexIVF_HNSW.cpp:802-814 pq_L2sqr: sequential m = 0..code_size-1 (unrolled by 4 there). */
+#ifndef ORC_OFAST_ORDER
 static float adc_sum(const float *tab, const uint8_t *code, size_t code_size)
 {
     float result = 0.0f;
@@ -553,6 +579,20 @@ static float adc_sum(const float *tab, const uint8_t *code, size_t code_size)
         result = result + tab[256 * m + code[m]];
     return result;
 }
+#else
+/* g++ 11.4 -Ofast on that loop: result += (t0 + t1) + (t2 + t3) per group of four (see orc_l2sqr above). */
+static float adc_sum(const float *tab, const uint8_t *code, size_t code_size)
+{
+    float result = 0.0f;
+    for (size_t m = 0; m + 4 <= code_size; m += 4) {
+        float a = tab[256 * m + code[m]] + tab[256 * (m + 1) + code[m + 1]];
+        float b = tab[256 * (m + 2) + code[m + 2]] + tab[256 * (m + 3) + code[m + 3]];
+        float c = a + b;
+        result = result + c;
+    }
+    return result;
+}
+#endif
 
 typedef struct {
     float *query;   /* rotated query (do_opq) */

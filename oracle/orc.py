@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborc.so")
+# ORC_LIB: another build of the same source (liborc_ofast.so: the float associations of the reference's -Ofast binary,
+# tests/test_oracle_float_order.py); the default is the source-order contract
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborc.so")
 
 
 class OrcIndex(C.Structure):

@@ -250,6 +250,87 @@ def test_replica_groups_of_list_shards(tmp_path):
         assert os.path.exists(os.path.join(str(tmp_path), "rank%d.ok" % r)), os.listdir(str(tmp_path))
 
 
+def _worker_class(rank, world, port, out_dir, tiny_cap):
+    """The REAL ShardedSearcher (ivf-hnsw_amd/distributed.py) over gloo ranks, each driving a CPU stand-in shard
+    (tests/fake_shard.py): k = 1 (MIN / MAX all-reduce), k = 10 ascending and in faiss heap-array order, spatial owner
+    table, against the unsharded oracle.  tiny_cap: one rank's candidate streams overflow a forced capacity -- every
+    rank must raise (none may be left waiting in a collective)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import importlib
+    import synth
+    from fake_shard import FakeShard
+    ge.load_pkg()
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    c = synth.make_corpus(seed=53, nc=96, d=64, M=8, n_base=6000, nq=21, efConstruction=60)
+    nprobe, max_codes, ef = 12, 700, 32
+    ox = synth.oracle_index(c)
+    sizes = np.diff(c["offsets"].astype(np.int64))
+    owner = D.partition_lists(c["centroids"], sizes, world, "spatial")
+    nq = len(c["queries"])
+    cpu = torch.device("cpu")
+    d_q = torch.from_numpy(c["queries"].copy())
+    ok, note = True, ""
+    if tiny_cap:
+        # shard 0 owns everything but one short list: only ITS streams pass the (forced, common) capacity of 64
+        owner = np.zeros(c["nc"], np.uint32)
+        small = np.where((sizes > 0) & (sizes <= 64))[0]
+        owner[int(small[0])] = 1
+        sh = FakeShard(c, ox, rank, owner, D.pack_keys, D.unpack_keys)
+        s = D.ShardedSearcher(sh, rank, world, nq, nprobe, cpu, k=10, stream_cap=64)
+        dd = torch.empty((nq, 10), dtype=torch.float32)
+        ll = torch.empty((nq, 10), dtype=torch.int64)
+        try:
+            s.step(d_q, dd, ll, max_codes, ef, heap_order=True)
+            ok, note = False, "no overflow raised"
+        except RuntimeError as e:
+            ok, note = "exceeded" in str(e), str(e)
+        dist.barrier()   # reached by every rank only if none hangs in the step's collectives
+    else:
+        for k, heap in ((1, False), (10, False), (10, True)):
+            ox.set_params(nprobe, max_codes, ef)
+            ref_d, ref_l, _, _, _ = ox.search_batch(c["queries"], k=k)
+            sh = FakeShard(c, ox, rank, owner, D.pack_keys, D.unpack_keys)
+            s = D.ShardedSearcher(sh, rank, world, nq, nprobe, cpu, k=k)
+            dd = torch.empty((nq, k), dtype=torch.float32)
+            ll = torch.empty((nq, k), dtype=torch.int64)
+            s.step(d_q, dd, ll, max_codes, ef, heap_order=heap)
+            lab, dis = ll.numpy(), dd.numpy()
+            if k == 1 or heap:
+                good = np.array_equal(lab, ref_l) and np.array_equal(dis.view(np.uint32), ref_d.view(np.uint32))
+            else:
+                good = np.array_equal(np.sort(lab, 1), np.sort(ref_l, 1)) and bool((np.diff(dis, axis=1) >= 0).all())
+            ok &= bool(good)
+            note += "k=%d heap=%s %s; " % (k, heap, good)
+    open(os.path.join(out_dir, "rank%d.%s" % (rank, "ok" if ok else "fail")), "w").write(note + "\n")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_searcher_class_over_gloo_ranks(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000) + world * 13
+    mp.spawn(_worker_class, args=(world, port, str(tmp_path), False), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("rank%d.ok" % r)), open(tmp_path / ("rank%d.fail" % r)).read()
+
+
+def test_stream_overflow_on_one_shard_raises_on_every_rank(tmp_path):
+    """a rank-local overflow test before the MAX all-reduce left the other ranks in the all-gathers."""
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000)
+    mp.spawn(_worker_class, args=(2, port, str(tmp_path), True), nprocs=2, join=True)
+    for r in range(2):
+        assert os.path.exists(tmp_path / ("rank%d.ok" % r)), open(tmp_path / ("rank%d.fail" % r)).read()
+
+
 def test_key_packing_orders_like_distance_then_position():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge

@@ -148,47 +148,46 @@ def test_config3_grouping_pruning_opq(grouping1b):
     _check_sample(g, tb, vectors, q[:256], 32, 10000, 80, opq_A=A, gt=gt, pruning=False)
 
 
-def test_config3_as_eight_shards(pkg, grouping1b):
-    """configs[3] "codes sharded across 8 MI355X", rehearsed as 8 shard handles on the one GPU: every shard holds the
-    lists an owner table gives it, all derive the same global plan, the packed keys are MIN-merged (torch.minimum
-    here, an RCCL all-reduce on the node: ivf-hnsw_amd/distributed.py) and the owner resolves each label."""
+def _as_eight_shards(pkg, g, tb, vectors, A, gt, d, nprobe, max_codes, ef, pruning, owner, q):
+    """The index of handle `g` again as 8 shard handles on the one GPU: every shard holds the lists the owner table gives
+    it, all derive the same global plan, the packed keys are MIN-merged (torch.minimum here, an RCCL all-reduce on the
+    node: ivf-hnsw_amd/distributed.py) and the owner resolves each label.  Must equal the one-handle result bit for bit."""
     import torch
-    g, tb, gt, A, vectors = grouping1b
-    world, nq = 8, 2048
-    q = _queries(tb, nq, 23, 12.0)
+    world, nq = 8, len(q)
     dev = torch.device("cuda", 0)
     d_q = torch.from_numpy(q).to(dev)
     d_ref = torch.empty((nq, 1), dtype=torch.float32, device=dev)
     l_ref = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-    g.search_dev(nq, 1, d_q, d_ref, l_ref, 32, 10000, efSearch=80, do_pruning=True)
+    g.search_dev(nq, 1, d_q, d_ref, l_ref, nprobe, max_codes, efSearch=ef, do_pruning=pruning)
     g.sync()
     n_ref = g.last_scan_counts()[0]
     # coarse stage once, on rotated queries, handed to every shard (the search2 split)
     xr = torch.empty_like(d_q)
     g.rotate_dev(nq, d_q, xr)
-    d_cid = torch.empty((nq, 32), dtype=torch.int32, device=dev)
-    d_cd = torch.empty((nq, 32), dtype=torch.float32, device=dev)
-    g.coarse_dev(nq, xr, 32, 80, d_cid, d_cd)
+    d_cid = torch.empty((nq, nprobe), dtype=torch.int32, device=dev)
+    d_cd = torch.empty((nq, nprobe), dtype=torch.float32, device=dev)
+    g.coarse_dev(nq, xr, nprobe, ef, d_cid, d_cd)
     g.sync()
-    owner = ((np.arange(tb["nc"], dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(9)) % np.uint64(world)
-    owner = owner.astype(np.uint32)
-    merged, shards, total = None, [], 0
+    merged, shards, total, per_rank = None, [], 0, []
     for r in range(world):
         s = pkg.GpuIndex(0)
-        s.upload_ivf_synthetic(128, 16, tb["offsets"], tb["centroid_norms"], tb["pq_centroids"], tb["norm_table"],
+        s.upload_ivf_synthetic(d, 16, tb["offsets"], tb["centroid_norms"], tb["pq_centroids"], tb["norm_table"],
                                tb["code_seed"], opq_A=A, shard_rank=r, shard_world=world, list_owner=owner)
         s.upload_quantizer(tb["counts"], tb["links"], vectors, 0)
-        s.upload_grouping(64, gt["alphas"], gt["nn_centroid_idxs"], gt["subgroup_sizes"], gt["inter_centroid_dists"])
+        if gt is not None:
+            s.upload_grouping(64, gt["alphas"], gt["nn_centroid_idxs"], gt["subgroup_sizes"], gt["inter_centroid_dists"])
         dd = torch.empty((nq, 1), dtype=torch.float32, device=dev)
         ll = torch.empty((nq, 1), dtype=torch.int64, device=dev)
         kk = torch.empty((nq, 1), dtype=torch.int64, device=dev)
-        s.search_dev(nq, 1, d_q, dd, ll, 32, 10000, d_coarse_ids=d_cid, d_coarse_dists=d_cd, do_pruning=True,
+        s.search_dev(nq, 1, d_q, dd, ll, nprobe, max_codes, d_coarse_ids=d_cid, d_coarse_dists=d_cd, do_pruning=pruning,
                      d_out_keys=kk)
         s.sync()
-        total += s.last_scan_counts()[0]
+        per_rank.append(s.last_scan_counts()[0])
+        total += per_rank[-1]
         merged = kk if merged is None else torch.minimum(merged, kk)
         shards.append((s, dd, ll))
     assert total == n_ref  # the shards partition the scanned codes exactly
+    assert min(per_rank) > 0
     label = torch.full((nq, 1), -1, dtype=torch.int64, device=dev)
     for s, dd, ll in shards:
         s.resolve_keys_dev(nq, 1, merged, dd, ll)
@@ -198,6 +197,19 @@ def test_config3_as_eight_shards(pkg, grouping1b):
     assert torch.equal(shards[-1][1].view(torch.int32), d_ref.view(torch.int32))
     for s, _, _ in shards:
         s.close()
+
+
+def test_config3_as_eight_shards(pkg, grouping1b):
+    """configs[3] "codes sharded across 8 MI355X", rehearsed as 8 shard handles behind the load-balanced SPATIAL owner
+    table the multi-GPU bench can run with (distributed.partition_lists over the 993 127 centroids)."""
+    import importlib
+    D = importlib.import_module("ivfhnsw_amd.distributed")
+    g, tb, gt, A, vectors = grouping1b
+    sizes = np.diff(tb["offsets"].astype(np.int64))
+    load = D.expected_list_load(sizes, tb["counts"], tb["links"])
+    owner = D.partition_lists(tb["centroids"], sizes, 8, "spatial", load=load)
+    assert set(owner.tolist()) == set(range(8))
+    _as_eight_shards(pkg, g, tb, vectors, A, gt, 128, 32, 10000, 80, True, owner, _queries(tb, 2048, 23, 12.0))
 
 
 def test_config4_deep1b_opq(pkg):
@@ -213,5 +225,9 @@ def test_config4_deep1b_opq(pkg):
         q = _queries(tb, 2048, 24, 0.03)
         _check_sample(g, tb, tb["centroids"], q[:NSAMPLE], 128, 100000, 130, opq_A=A)
         _check_properties(g, q, 128, 100000, 130, N1B)
+        # configs[4] "8 MI355X shard": the same index as 8 shard handles, lists dealt by a hash of the list number
+        owner = (((np.arange(tb["nc"], dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(9)) % np.uint64(8))
+        _as_eight_shards(pkg, g, tb, tb["centroids"], A, None, 96, 128, 100000, 130, False, owner.astype(np.uint32),
+                         q[:1024])
     finally:
         g.close()
