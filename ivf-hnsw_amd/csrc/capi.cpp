@@ -750,11 +750,7 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
             return (e && atoi(e) == 0) ? 0 : 1;
         }();
         h->gr.merge_admissions = merge;
-        static const int skippad = [] {
-            const char *e = getenv("IVFHNSW_WALK_SKIPPAD");
-            return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : 1;
-        }();
-        h->gr.skip_padding = skippad;
+        h->gr.skip_padding = 1;
     }
     {
         // IVFHNSW_WALK_LATE_VISIT: 1 always, 0 never, unset = where it pays -- graphs whose ids need more than 8 tag
@@ -829,12 +825,6 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         return fail(IVFHNSW_ERR_INVALID, "nq too large");
     // one visited bitmap per query in flight
     const size_t words = ((((size_t)h->gr.n + 31) / 32) + 3) & ~(size_t)3;
-    // IVFHNSW_WALK=4 selects the four-queries-per-wavefront kernel (kernels_hnsw4.hip): exact, but measured
-    // slower (3.3 vs 2.05 ms per 10 k queries) -- kept for further work, off by default
-    static const bool one_per_wave = [] {
-        const char *e = getenv("IVFHNSW_WALK");
-        return !(e && atoi(e) == 4);
-    }();
     StageScope sc(h, IVFHNSW_STAGE_COARSE);
     // few queries (the reference's drivers: one per call): a workgroup per query on the fat graph, when it was prepared
     static const size_t lat_max_nq = [] {
@@ -849,23 +839,8 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         h->walk_zero_done = nullptr;
         return IVFHNSW_OK;
     }
-    if (efSearch <= 256 && !one_per_wave) {
-        // four queries per wavefront (kernels_hnsw4.hip)
-        const int nwaves = (int)std::min<size_t>((nq + 3) / 4, (size_t)coarse4_waves_resident());
-        if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nwaves * 4)))
-            return rc;
-        HIP_TRY(launch_coarse4(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                               d_coarse_dists, h->w_visited.as<uint32_t>(), words, nwaves,
-                               h->w_status.as<uint32_t>(), h->w_status.as<uint32_t>() + 1));
-        h->visited_zero = false; // that form's bitmaps stay as its last queries left them
-    } else {
-        // IVFHNSW_WALK_SLOTS caps the wavefronts the walk is launched with (experiments on the rounds a batch takes)
-        static const size_t slot_cap = [] {
-            const char *e = getenv("IVFHNSW_WALK_SLOTS");
-            const long v = e ? atol(e) : 0;
-            return v > 0 ? (size_t)v : (size_t)-1;
-        }();
-        const int nslots = (int)std::min<size_t>(std::min<size_t>(nq, slot_cap), (size_t)coarse_slots_for((int)efSearch));
+    {
+        const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
         if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
             return rc;
         if (h->w_visited.p != h->visited_zero_ptr || h->w_visited.bytes != h->visited_zero_bytes) {
@@ -1431,15 +1406,12 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     const uint64_t nseg_all = (uint64_t)h->t.nc * (h->has_group ? (uint64_t)h->g.nsubc : 1);
     const int seg_hint = (int)std::min<uint64_t>(1u << 20, nseg_all ? (h->n_local * h->t.shard_world) / nseg_all : 0);
     const bool heap = p->heap_order && k > 1;
-    // k = 1 on the common shapes: table and scan fused, the table never leaves the chip (kernels_scan2.hip)
-    const bool short_segments = seg_hint > 0 && seg_hint <= 48;
-    const bool fused = k == 1 && scan_fused_supported(h->t, short_segments);
     // small batches: split each query over several workgroups so the chip still fills
     int nsplit = 1;
     if (k == 1 && nq < 1024)
         nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
     // list shards: table and scan in one software-pipelined kernel, the table never leaves the chip (kernels_scan3.hip)
-    const bool pipe = k == 1 && !fused && !h->has_group && !heap &&
+    const bool pipe = k == 1 && !h->has_group && !heap &&
                       scan_pipe_supported(h->t, max_seg, (int)nq, nsplit, h->n_local > 0);
     // one GPU, IVFADC: plan and tables are independent of each other and go in ONE launch (kernels_search.hip
     // plan_lut_kernel; IVFHNSW_PLAN_LUT=0 keeps them apart)
@@ -1448,9 +1420,9 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         return !(e && *e && atoi(e) == 0);
     }();
     const int ds = h->t.dsub;
-    const bool plan_lut = plan_lut_on && !h->has_group && !fused && !pipe && h->t.shard_world == 1 &&
+    const bool plan_lut = plan_lut_on && !h->has_group && !pipe && h->t.shard_world == 1 &&
                           (ds == 4 || ds == 6 || ds == 8 || ds == 12 || ds == 16);
-    if (!fused && !pipe && (rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
+    if (!pipe && (rc = h->w_luts.ensure(nq * (size_t)M * 256 * sizeof(float))))
         return rc;
     // 3. plan (IndexIVF_HNSW.cpp:267-292 / IndexIVF_HNSW_Grouping.cpp:222-353)
     if (plan_lut) {
@@ -1475,7 +1447,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         }
     }
     // 4. table (IndexIVF_HNSW.cpp:262)
-    if (!fused && !pipe && !plan_lut) {
+    if (!pipe && !plan_lut) {
         StageScope sc(h, IVFHNSW_STAGE_LUT);
         HIP_TRY(launch_lut(h->stream, h->t, xq, h->w_luts.as<float>(), (int)nq, h->w_hdr.as<PlanHdr>()));
     }
@@ -1490,15 +1462,8 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
             return rc;
     }
     {
-        if (fused && (rc = h->w_counter.ensure(sizeof(uint32_t))))
-            return rc;
         StageScope sc(h, IVFHNSW_STAGE_SCAN);
-        if (fused) {
-            HIP_TRY(launch_scan_fused(h->stream, h->t, xq, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
-                                      h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, nsplit, h->w_keys.as<uint64_t>(),
-                                      h->w_counter.as<uint32_t>(), short_segments));
-            h->last_scan_kernel = short_segments ? "scan_fused_kernel (short segments)" : "scan_fused_kernel";
-        } else if (pipe) {
+        if (pipe) {
             HIP_TRY(launch_scan_pipe(h->stream, h->t, xq, h->w_segs.as<Seg>(), h->w_lpos.as<uint32_t>(),
                                      h->w_hdr.as<PlanHdr>(), max_seg, (int)nq, h->w_keys.as<uint64_t>()));
             h->last_scan_kernel = "scan_pipe_kernel";

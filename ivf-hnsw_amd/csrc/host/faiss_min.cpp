@@ -24,16 +24,25 @@ namespace faiss {
 
 namespace {
 
-// Training runs on the device (ivfhnsw_gpu_pq_train, ivfhnsw_gpu_xty): a handle for the duration of one call.
-// There is no host fallback: without a gfx950 device training fails, like every other device entry point.
+// Training runs on the device (ivfhnsw_gpu_pq_train, ivfhnsw_gpu_xty) through ONE handle per process, created at the
+// first training call and kept (its stream, status word and the t_x / t_y buffers are reused by every Lloyd batch and
+// every OPQ iteration; round 2 created and destroyed a handle per iteration).  Never destroyed: a static destructor
+// would run after the HIP runtime's own.  There is no host fallback: without a gfx950 device training fails, like every
+// other device entry point.
 struct TrainDevice {
     ivfhnsw_gpu *h = nullptr;
     TrainDevice()
     {
-        if (ivfhnsw_gpu_create(0, &h))
+        static ivfhnsw_gpu *shared = [] {
+            ivfhnsw_gpu *p = nullptr;
+            if (ivfhnsw_gpu_create(0, &p))
+                p = nullptr;
+            return p;
+        }();
+        if (!shared)
             throw std::runtime_error(std::string("code-book training needs the device: ") + ivfhnsw_gpu_last_error());
+        h = shared;
     }
-    ~TrainDevice() { ivfhnsw_gpu_destroy(h); }
     TrainDevice(const TrainDevice &) = delete;
     TrainDevice &operator=(const TrainDevice &) = delete;
 };

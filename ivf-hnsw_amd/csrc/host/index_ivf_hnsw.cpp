@@ -202,6 +202,10 @@ void IndexIVF_HNSW::upload_graph()
     upload_graph_to(gpu_);
     graph_dirty_ = false;
     graph_uploaded_for_ = quantizer;
+    // ivfhnsw_gpu_upload_quantizer discards the fat copy the latency walk reads: the next one-query search() must
+    // prepare it again even though the quantizer POINTER is the one it was prepared for (add_batch, read and
+    // rotate_quantizer all come through here)
+    latency_for_ = nullptr;
 }
 
 void IndexIVF_HNSW::upload_graph_to(ivfhnsw_gpu *handle)
@@ -296,6 +300,16 @@ void IndexIVF_HNSW::device_search(size_t nq, size_t k, const float *x, const idx
     }
     if (nq == 0)
         return;
+    // the shard step holds one plan per call: at most 2^17 queries (2^14 in heap order, k > 1), like the unsharded
+    // entry point, which slices larger batches itself
+    const size_t chunk = k > 1 ? ((size_t)1 << 14) : ((size_t)1 << 17);
+    if (nq > chunk) {
+        for (size_t q0 = 0; q0 < nq; q0 += chunk)
+            device_search(std::min(chunk, nq - q0), k, x + q0 * d, coarse_ids ? coarse_ids + q0 * nprobe_ : nullptr,
+                          coarse_dists ? coarse_dists + q0 * nprobe_ : nullptr, nprobe_, max_codes_, pruning,
+                          distances + q0 * k, labels + q0 * k);
+        return;
+    }
     const size_t world = nshards();
     // the coarse stage once, on shard 0 (the rotated query walks the rotated graph, IndexIVF_HNSW.cpp:240,248)
     std::vector<idx_t> cid_own;

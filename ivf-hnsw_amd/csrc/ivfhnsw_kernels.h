@@ -110,7 +110,7 @@ struct GraphTables {
     // NULL until ivfhnsw_gpu_prepare_latency builds it.
     const float *fat;
     int visited_clean;    // walk (set by its launcher): the global visited bitmaps are zero on entry and left zero
-    int skip_padding;     // walk: the filter skips the arithmetic of rows beyond the link count (A/B knob IVFHNSW_WALK_SKIPPAD)
+    int skip_padding;     // walk: the filter skips the arithmetic of rows beyond the link count (always on since round 3)
     int merge_admissions; // walk: insert a pass's admitted rows in one step (A/B knob IVFHNSW_WALK_MERGE=0)
     int links_unique;     // no id twice in a link list: survivors of the filter may enter the visited set late
 };
@@ -143,15 +143,10 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
                        // k = 1: let the scan resolve the winner's label itself where one workgroup sees the whole query;
                        // *did_select tells whether it did (else launch_select has to run)
                        float *sel_dist = nullptr, int64_t *sel_labels = nullptr, bool *did_select = nullptr); // expected codes per plan segment (0 = unknown): picks the scan form
-// table + scan in one persistent kernel, code book in registers (kernels_scan2.hip); k = 1, PQ16 / PQ8 at d = 128, 96
 // table + scan pipelined over queries, for list shards (kernels_scan3.hip)
 bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes);
 hipError_t launch_scan_pipe(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
                             const PlanHdr *hdr, int max_seg, int nq, uint64_t *keys);
-bool scan_fused_supported(const IvfTables &t, bool short_segments);
-hipError_t launch_scan_fused(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
-                             const PlanHdr *hdr, int max_seg, int nq, int nsplit, uint64_t *keys, uint32_t *counter,
-                             bool short_segments); // short_segments: sub-group plans (Grouping), see kernels_scan2.hip
 // plan + table + scan + select of a small IVFADC batch in one launch (kernels_tail.hip); keys_inv [nq] and done [nq] zeroed
 bool ivf_tail_supported(const IvfTables &t, int nprobe, int k);
 hipError_t launch_ivf_tail(hipStream_t s, const IvfTables &t, const float *xq, const uint32_t *cid, const float *cd,
@@ -182,11 +177,6 @@ hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat);
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                                  uint32_t *coarse_ids, float *coarse_dists, uint32_t *status,
                                  uint64_t *zero_keys = nullptr, uint32_t *zero_done = nullptr); // [nq] words to clear
-// four queries per wavefront (ef <= 256)
-hipError_t launch_coarse4(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
-                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
-                          size_t visited_words_per_slot, int nwaves, uint32_t *status, uint32_t *next_query);
-int coarse4_waves_resident();
 // bits of the device status word
 constexpr uint32_t kStatusHnswTieOverflow = 1u;
 constexpr uint32_t kStatusTopkStreamOverflow = 2u;

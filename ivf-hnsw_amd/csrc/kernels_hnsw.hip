@@ -886,12 +886,9 @@ int coarse_slots_for(int ef)
     // Exactly the wavefronts that can be resident (256 CUs x 4 SIMDs x the waves per SIMD the kernel is built for;
     // its registers allow no more): blocks beyond that only start when a slot frees up, find the queue empty and
     // cost their prologue -- 1.205 vs 1.189 ms per 10 k queries with 8192 instead of 4096 blocks.
-    static const int occ = [] {
-        const char *e = getenv("IVFHNSW_WALK_OCC");
-        const int v = e ? atoi(e) : 4;
-        return (v == 5 || v == 6) ? v : 4;
-    }();
-    const int waves_per_simd = nch <= 4 ? occ : (nch <= 8 ? 4 : 3);
+    // (builds for 5 and 6 waves per SIMD were measured -- 1.52 / 1.50 ms against 1.50 at 2^17 nodes, 1.51 / 1.68 against
+    // 1.37 at 993 127 -- and removed in round 3 with their IVFHNSW_WALK_OCC knob)
+    const int waves_per_simd = nch <= 8 ? 4 : 3;
     return 256 * 4 * waves_per_simd;
 }
 
@@ -911,13 +908,9 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
     // Waves per SIMD the kernel is built for (register budget and visited-set size follow from it).  Measured
     // on MI355X (100M / 2^17-centroid workload, ef 80) with the LDS padded to hold 2, 3, 4 waves per SIMD
     // resident: 2.61, 1.90, 1.54 ms per 10 k queries = 0.48 + 4.26 / waves -- the walk is latency bound per wave.
-    static const int occ = [] {
-        const char *e = getenv("IVFHNSW_WALK_OCC");
-        const int v = e ? atoi(e) : 4;
-        return (v == 5 || v == 6) ? v : 4;
-    }();
+    constexpr int occ = 4;
     const int nch = (ef + 63) / 64;
-    const int occ_eff = (nch <= 4 && g.nbrows) ? occ : 4;
+    const int occ_eff = 4;
     uint32_t nbk = (uint32_t)vis_buckets(occ_eff);
     // the LDS visited set needs 16-bit tags at most; IVFHNSW_WALK_VIS=bitmap forces the global bitmap (A/B runs)
     static const bool force_bitmap = [] {
@@ -939,15 +932,10 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
     } else if (tagw == 10) {
         tagw = 12; // the 10-bit form exists for 4 waves per SIMD only
     }
-    // occupancy experiments only: extra LDS per wavefront lowers the number of resident waves
-    static const size_t lds_pad = [] {
-        const char *e = getenv("IVFHNSW_WALK_LDSPAD");
-        return e ? (size_t)atoi(e) : (size_t)0;
-    }();
     const size_t shm = (size_t)(g.d + ((g.qrows && !g.nbrows) ? g.d : 0)) * sizeof(float) + 512 +
                        (size_t)(kTailCap + ((ef <= 256 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) *
                            sizeof(unsigned long long) +
-                       (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0) + lds_pad;
+                       (tagw ? (size_t)nbk * sizeof(unsigned long long) : 0);
     const int fmode = g.nbrows ? (g.links_unique && tagw ? 3 : 2) : g.qrows ? 1 : 0;
     // the global bitmaps: with the LDS set (tagw != 0) they are the overflow store, zero between launches -- cleared
     // here once if the caller cannot vouch for them; the bitmap-only forms wipe per query and leave them used
@@ -990,15 +978,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
         else                           \
             IVFHNSW_WALK_T(N, W, 0);   \
     } while (0)
-#define IVFHNSW_WALK_N(N)              \
-    do {                               \
-        if (occ == 6)                  \
-            IVFHNSW_WALK(N, 6);        \
-        else if (occ == 5)             \
-            IVFHNSW_WALK(N, 5);        \
-        else                           \
-            IVFHNSW_WALK(N, 4);        \
-    } while (0)
+#define IVFHNSW_WALK_N(N) IVFHNSW_WALK(N, 4)
     static const bool stamps = [] {
         const char *e = getenv("IVFHNSW_WALK_STAMPS");
         return e && atoi(e) == 1;

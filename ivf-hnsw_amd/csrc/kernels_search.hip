@@ -353,30 +353,17 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
     return v;
 }
 
-// LDS bank replication (REP > 1): with one copy of the table the 32 lanes of a half-wave gather from 32
-// banks at random (expected worst bank ~3.5 deep per ds_read_b32).  With REP copies, copy r lives only in
-// banks [r*32/REP, (r+1)*32/REP) and lane l uses copy (l % 32) / (32/REP), so 32/REP lanes share 32/REP
-// banks (expected worst bank ~2.4 deep at REP = 4): entry e of copy r of sub-table m is the dword
-// m*256*REP + (e / G)*32 + r*G + e % G with G = 32/REP.
-template <int REP> __device__ __forceinline__ uint32_t lut_byte_offset(uint32_t e, uint32_t rbase)
-{
-    if constexpr (REP == 1)
-        return e << 2;
-    else if constexpr (REP == 2)
-        return ((e & 0xF0u) << 3) | ((e & 15u) << 2) | rbase;
-    else
-        return ((e & 0xF8u) << 4) | ((e & 7u) << 2) | rbase;
-}
-
-template <int CS, int REP>
-__device__ __forceinline__ float adc_sum_rep(const float *s_lut, const uint32_t (&w)[CS > 0 ? CS / 4 : 1], uint32_t rbase)
+// The ADC sum of one code from the query's table in LDS, m = 0..CS-1 in order (IndexIVF_HNSW.cpp:802-814).  (Replicating
+// the table over disjoint LDS banks was built and measured in round 1 -- no gain, DESIGN.md 3.1 -- and removed in round 3.)
+template <int CS>
+__device__ __forceinline__ float adc_sum_lds(const float *s_lut, const uint32_t (&w)[CS > 0 ? CS / 4 : 1])
 {
     float sum = 0.0f;
     const char *base = reinterpret_cast<const char *>(s_lut);
 #pragma unroll
     for (int m = 0; m < CS; m++) {
         const uint32_t e = (w[m >> 2] >> ((m & 3) * 8)) & 0xffu;
-        sum = __fadd_rn(sum, *reinterpret_cast<const float *>(base + m * 1024 * REP + lut_byte_offset<REP>(e, rbase)));
+        sum = __fadd_rn(sum, *reinterpret_cast<const float *>(base + m * 1024 + (e << 2)));
     }
     return sum;
 }
@@ -414,7 +401,7 @@ __device__ __forceinline__ void sel_write(const SelOut &so, int q, unsigned long
     so.labels[q] = lb;
 }
 
-template <int CS, int SEGCAP, int U, int REP, int THREADS>
+template <int CS, int SEGCAP, int U, int THREADS>
 __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restrict__ codes,
                                                           const uint8_t *__restrict__ norm_codes,
                                                           const float *__restrict__ luts,
@@ -425,7 +412,7 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                                                           unsigned long long *__restrict__ keys, int cs_rt, SelOut so)
 {
     // CS == 0: run-time code size cs_rt, table in dynamic LDS (code sizes without an instantiation of their own)
-    __shared__ __attribute__((aligned(16))) float s_lut_fixed[(CS > 0 ? CS : 1) * 256 * REP];
+    __shared__ __attribute__((aligned(16))) float s_lut_fixed[(CS > 0 ? CS : 1) * 256];
     extern __shared__ __attribute__((aligned(16))) float s_lut_dyn[];
     float *s_lut = CS > 0 ? s_lut_fixed : s_lut_dyn;
     const int csz = CS > 0 ? CS : cs_rt;
@@ -453,36 +440,17 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
 
     {
         const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * csz * 256);
-        if constexpr (REP == 1) {
-            // global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16): the table never
-            // passes through VGPRs, and a ds_write_b128 costs the LDS pipe 13 cycles where the DMA's write costs 4
-            // -- the scan is bound by that pipe
-            const int lane = tid & 63;
-            for (int i = tid; i < csz * 64; i += THREADS)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + i),
-                    (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(s_lut) + (i - lane)), 16, 0, 0);
-        } else {
-            constexpr int G = 32 / REP; // dwords of one copy inside a 32-dword bank row
-            char *base = reinterpret_cast<char *>(s_lut);
-            for (int i = tid; i < CS * 64; i += THREADS) {
-                const float4 v = src[i];
-                const int m = i >> 6, e = (i & 63) * 4; // entries e..e+3 of sub-table m
-                char *row = base + m * 1024 * REP + (e / G) * 128 + (e % G) * 4;
-                // copy order rotated per lane so that the 8 lanes a ds_write_b128 services together cover
-                // the 8 distinct 16-byte slots of a 128-byte bank row (conflict-free)
-                const int r0 = (i / (G / 4)) % REP;
-#pragma unroll
-                for (int j = 0; j < REP; j++) {
-                    const int r = (r0 + j) % REP;
-                    *reinterpret_cast<float4 *>(row + r * G * 4) = v;
-                }
-            }
-        }
+        // global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16): the table never
+        // passes through VGPRs, and a ds_write_b128 costs the LDS pipe 13 cycles where the DMA's write costs 4
+        // -- the scan is bound by that pipe
+        const int lane = tid & 63;
+        for (int i = tid; i < csz * 64; i += THREADS)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src + i),
+                (__attribute__((address_space(3))) void *)(reinterpret_cast<float4 *>(s_lut) + (i - lane)), 16, 0, 0);
         for (int i = tid; i < 256; i += THREADS)
             s_norm[i] = norm_table[i];
     }
-    const uint32_t rbase = REP == 1 ? 0u : (uint32_t)(((tid & 31) / (32 / REP)) * (32 / REP) * 4);
 
     const Seg *sq = segs + (size_t)q * max_seg;
     const uint32_t *lq = lpos + (size_t)q * max_seg;
@@ -563,7 +531,7 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
                 if (ok[u]) {
                     float sum;
                     if constexpr (CS > 0)
-                        sum = adc_sum_rep<CS, REP>(s_lut, w[u].w, rbase);
+                        sum = adc_sum_lds<CS>(s_lut, w[u].w);
                     else
                         sum = w[u].sum;
                     const float tt = __fadd_rn(ct[u], s_norm[nb[u]]);
@@ -597,101 +565,9 @@ __global__ __launch_bounds__(THREADS) void scan_k1_kernel(const uint8_t *__restr
     }
 }
 
-// The same scan for plans made of SHORT segments (Grouping: a sub-group holds ~12 codes at the reference's
-// nsubc 64): with positions dealt to lanes as above nearly every code starts in a new segment and pays a binary
-// search in the LDS plan.  Here a group of G lanes owns a whole segment (lane i its codes i, i+G, ...), groups take
-// segments round-robin, two segments per step so that two loads per lane are in flight: one plan read per
-// segment instead of a search per code.  Same keys, so same winner.
-template <int CS, int G>
-__global__ __launch_bounds__(256) void scan_k1_short_kernel(const uint8_t *__restrict__ codes,
-                                                            const uint8_t *__restrict__ norm_codes,
-                                                            const float *__restrict__ luts,
-                                                            const float *__restrict__ norm_table,
-                                                            const Seg *__restrict__ segs,
-                                                            const PlanHdr *__restrict__ hdr, int max_seg, int nsplit,
-                                                            unsigned long long *__restrict__ keys)
-{
-    __shared__ __attribute__((aligned(16))) float s_lut[CS * 256];
-    __shared__ float s_norm[256];
-    __shared__ unsigned long long s_red[4];
-    const int tid = threadIdx.x;
-    const int q = blockIdx.x / nsplit;
-    const int split = blockIdx.x - q * nsplit;
-    const PlanHdr h = hdr[q];
-    if (h.total == 0)
-        return;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(luts + (size_t)q * CS * 256);
-        float4 *dst = reinterpret_cast<float4 *>(s_lut);
-        for (int i = tid; i < CS * 64; i += 256)
-            dst[i] = src[i];
-        s_norm[tid] = norm_table[tid];
-    }
-    __syncthreads();
-    constexpr int NG = 256 / G; // groups per block
-    const int gid = tid / G, li = tid % G;
-    const Seg *sq = segs + (size_t)q * max_seg;
-    unsigned long long best = kKeyInit;
-    const uint32_t stride = (uint32_t)NG * nsplit;
-    for (uint32_t s0 = (uint32_t)split * NG + gid; s0 < h.nseg; s0 += 2 * stride) {
-        const uint32_t s1 = s0 + stride;
-        const Seg a = sq[s0];
-        Seg b;
-        b.start = 0, b.len = 0, b.vpos = 0, b.cterm = 0.f;
-        if (s1 < h.nseg)
-            b = sq[s1];
-        const uint32_t n = a.len > b.len ? a.len : b.len;
-        for (uint32_t off = li; off < n; off += G) {
-            uint32_t wa[CS / 4], wb[CS / 4];
-            uint32_t na = 0, nb = 0;
-            const bool oa = off < a.len, ob = off < b.len;
-            if (oa) {
-                load_code_words<CS>(codes, a.start + off, wa);
-                na = norm_codes[a.start + off];
-            }
-            if (ob) {
-                load_code_words<CS>(codes, b.start + off, wb);
-                nb = norm_codes[b.start + off];
-            }
-            if (oa) {
-                const float sum = adc_sum<CS>(s_lut, wa);
-                const float dist = __fsub_rn(__fadd_rn(a.cterm, s_norm[na]), __fmul_rn(2.0f, sum));
-                if (dist < FLT_MAX) {
-                    const unsigned long long key =
-                        ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (a.vpos + off);
-                    best = key < best ? key : best;
-                }
-            }
-            if (ob) {
-                const float sum = adc_sum<CS>(s_lut, wb);
-                const float dist = __fsub_rn(__fadd_rn(b.cterm, s_norm[nb]), __fmul_rn(2.0f, sum));
-                if (dist < FLT_MAX) {
-                    const unsigned long long key =
-                        ((unsigned long long)f32_orderable(__fadd_rn(dist, 0.0f)) << 32) | (b.vpos + off);
-                    best = key < best ? key : best;
-                }
-            }
-        }
-    }
-    best = wave_min_u64(best);
-    if ((tid & 63) == 0)
-        s_red[tid >> 6] = best;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long m = s_red[0];
-#pragma unroll
-        for (int i = 1; i < 4; i++)
-            m = s_red[i] < m ? s_red[i] : m;
-        if (nsplit == 1)
-            keys[q] = m;
-        else if (m < kKeyInit)
-            atomicMin(&keys[q], m);
-    }
-}
-
-// The scan for SHORT segments, third form (Grouping: a sub-group holds ~16 codes at the reference's nsubc 64).
-// scan_k1_kernel deals positions to lanes but searches the segment of every position in the LDS plan;
-// scan_k1_short_kernel gives a lane group to every segment and leaves half the lanes idle -- and the scan is bound by
+// The scan for SHORT segments (Grouping: a sub-group holds ~16 codes at the reference's nsubc 64).
+// scan_k1_kernel deals positions to lanes but searches the segment of every position in the LDS plan; a lane group per
+// segment (round 1's scan_k1_short_kernel, tools/experiments/) leaves half the lanes idle -- and the scan is bound by
 // LDS instruction issue, so idle lanes cost as much as busy ones.  Here positions are dealt to lanes one code each
 // AND the segment comes from a bitmap: one bit per position of the plan chunk, set where a segment starts, plus the
 // number of starts before every 64-position word.  A wavefront's 64 positions share a word, so
@@ -881,17 +757,6 @@ __global__ __launch_bounds__(256) void scan_k1_bitmap_kernel(const uint8_t *__re
 static thread_local const char *g_scan_kernel_name = "";
 const char *last_scan_kernel_name() { return g_scan_kernel_name; }
 
-// tuning knob for A/B runs on the device: IVFHNSW_SCAN_REP = 1, 2 or 4 (LDS copies of the table)
-static int scan_rep_choice()
-{
-    static const int rep = [] {
-        const char *e = getenv("IVFHNSW_SCAN_REP");
-        const int v = e ? atoi(e) : 1;
-        return (v == 2 || v == 4) ? v : 1;
-    }();
-    return rep;
-}
-
 template <int CS>
 static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float *luts, const Seg *segs,
                                  const uint32_t *lpos, const PlanHdr *hdr, int max_seg, int nq, int nsplit,
@@ -901,17 +766,8 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
         so.ids = nullptr; // several workgroups per query meet in an atomic: nobody knows the winner
     dim3 grid((unsigned)nq * nsplit);
     auto *k64 = reinterpret_cast<unsigned long long *>(keys);
-    // short segments (Grouping sub-groups): a lane group per segment; IVFHNSW_SCAN_SHORT=0 keeps the position form
-    static const bool allow_short = [] {
-        const char *e = getenv("IVFHNSW_SCAN_SHORT");
-        return !(e && atoi(e) == 0);
-    }();
-    // IVFHNSW_SCAN_SHORT: 2 (default) = bitmap form, 1 = lane group per segment, 0 = the position form with its search
-    static const int short_form = [] {
-        const char *e = getenv("IVFHNSW_SCAN_SHORT");
-        return (e && *e) ? atoi(e) : 2;
-    }();
-    if (short_form >= 2 && seg_len_hint > 0 && seg_len_hint <= 48) {
+    // plans of short segments (Grouping sub-groups, ~16 codes): the bitmap form; whole lists: the position form
+    if (seg_len_hint > 0 && seg_len_hint <= 48) {
         g_scan_kernel_name = "scan_k1_bitmap_kernel";
         hipLaunchKernelGGL((scan_k1_bitmap_kernel<CS, 4>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table,
                            segs, lpos, hdr, max_seg, nsplit, k64, so);
@@ -919,57 +775,20 @@ static hipError_t launch_scan_cs(hipStream_t s, const IvfTables &t, const float 
             *did_select = so.ids != nullptr;
         return hipGetLastError();
     }
-    if (allow_short && seg_len_hint > 0 && seg_len_hint <= 48) {
-        g_scan_kernel_name = "scan_k1_short_kernel";
-#define IVFHNSW_SCAN_SHORT(GG)                                                                                        \
-    hipLaunchKernelGGL((scan_k1_short_kernel<CS, GG>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts, t.norm_table, \
-                       segs, hdr, max_seg, nsplit, k64)
-        if (seg_len_hint <= 8)
-            IVFHNSW_SCAN_SHORT(8);
-        else if (seg_len_hint <= 16)
-            IVFHNSW_SCAN_SHORT(16);
-        else if (seg_len_hint <= 32)
-            IVFHNSW_SCAN_SHORT(32);
-        else
-            IVFHNSW_SCAN_SHORT(64);
-#undef IVFHNSW_SCAN_SHORT
-        return hipGetLastError();
-    }
-#define IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, UU)                                                                     \
-    hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, UU, REP, THREADS>), grid, dim3(THREADS), 0, s, t.codes, t.norm_codes, \
-                       luts, t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, t.M, so)
-#define IVFHNSW_SCAN(SEGCAP, REP, THREADS)                 \
-    do {                                                   \
-        if (unroll == 2)                                   \
-            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 2);       \
-        else if (unroll == 8)                              \
-            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 8);       \
-        else                                               \
-            IVFHNSW_SCAN_U(SEGCAP, REP, THREADS, 4);       \
-    } while (0)
-    static const int unroll = [] {
-        const char *e = getenv("IVFHNSW_SCAN_U");
-        const int v = e ? atoi(e) : 4;
-        return (v == 2 || v == 8) ? v : 4;
-    }();
-    const int rep = CS <= 16 ? scan_rep_choice() : 1;
+#define IVFHNSW_SCAN(SEGCAP)                                                                                        \
+    hipLaunchKernelGGL((scan_k1_kernel<CS, SEGCAP, 4, 256>), grid, dim3(256), 0, s, t.codes, t.norm_codes, luts,    \
+                       t.norm_table, segs, lpos, hdr, max_seg, nsplit, k64, t.M, so)
     g_scan_kernel_name = "scan_k1_kernel";
     if (max_seg <= 64) {
-        if (rep == 4)
-            IVFHNSW_SCAN(64, 4, 512);
-        else if (rep == 2)
-            IVFHNSW_SCAN(64, 2, 256);
-        else
-            IVFHNSW_SCAN(64, 1, 256);
+        IVFHNSW_SCAN(64);
     } else if (max_seg <= 256) {
         // nprobe 65..256 (the DEEP1B preset probes 128 lists): a 5 KB plan instead of 20 KB keeps 7 workgroups
         // per CU resident instead of 4
-        IVFHNSW_SCAN(256, 1, 256);
+        IVFHNSW_SCAN(256);
     } else {
-        IVFHNSW_SCAN(1024, 1, 256);
+        IVFHNSW_SCAN(1024);
     }
 #undef IVFHNSW_SCAN
-#undef IVFHNSW_SCAN_U
     if (did_select)
         *did_select = so.ids != nullptr;
     return hipGetLastError();
@@ -1007,7 +826,7 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
         if (t.M % 4 || shm > kScanDynLdsMax)
             return hipErrorInvalidValue;
         g_scan_kernel_name = "scan_k1_kernel (run-time code size)";
-        auto *kern = scan_k1_kernel<0, 256, 2, 1, 256>;
+        auto *kern = scan_k1_kernel<0, 256, 2, 256>;
         static DynLdsState attr_set;
         if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr_set); e != hipSuccess)
             return e;

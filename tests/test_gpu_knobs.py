@@ -1,4 +1,4 @@
-"""Every A/B knob of the device path selects a different kernel form of the SAME computation.  The knobs are read
+"""Every knob the device path still has (round 3 removed the measured-slower kernel forms and theirs) selects a different kernel form of the SAME computation.  The knobs are read
 once per process, so each setting runs in its own child process on one seeded corpus; all of them must print the
 digest of the default path (coarse ids and distances, final labels and distances, grouping search included).
 """
@@ -57,17 +57,12 @@ def test_every_knob_setting_reproduces_the_default_path():
                 {"IVFHNSW_WALK_PREFILTER": "1"},     # gather form of the filter
                 {"IVFHNSW_WALK_MERGE": "0"},         # admissions one by one
                 {"IVFHNSW_WALK_VIS": "bitmap"},      # global visited bitmaps
-                {"IVFHNSW_WALK_OCC": "5"}, {"IVFHNSW_WALK_OCC": "6"},
                 {"IVFHNSW_WALK_TAGW": "10"}, {"IVFHNSW_WALK_TAGW": "12"}, {"IVFHNSW_WALK_TAGW": "16"},  # visited-set tag widths
                 # survivors of the filter entered into the visited set late (default only beyond 257 k nodes)
                 {"IVFHNSW_WALK_LATE_VISIT": "1"}, {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "10"},
                 {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "16"}, {"IVFHNSW_WALK_LATE_VISIT": "0"},
-                {"IVFHNSW_SCAN_SHORT": "0"},         # Grouping plans through the position form of the scan
-                {"IVFHNSW_SCAN_SHORT": "1"},         # ... through the lane-group-per-segment form (default: the bitmap form)
                 {"IVFHNSW_TAIL": "0"},               # small batches through the four separate launches
-                {"IVFHNSW_SCAN_FUSED": "1"},         # table + scan fused (kernels_scan2.hip), both segment forms
                 {"IVFHNSW_PLAN_GROUP4": "0"},        # Grouping plan by one wavefront per query (default: four)
                 {"IVFHNSW_PLAN_LUT": "0"},           # plan and tables as two launches (default: one, plan_lut_kernel)
-                {"IVFHNSW_SCAN_PIPE": "1"},          # table + scan pipelined over queries (kernels_scan3.hip), one shard too
-                {"IVFHNSW_SCAN_U": "2"}, {"IVFHNSW_SCAN_REP": "2"}):
+                {"IVFHNSW_SCAN_PIPE": "1"}):         # table + scan pipelined over queries (kernels_scan3.hip), one shard too
         assert _run(env) == base, env

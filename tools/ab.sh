@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B runs of bench.py on the GPU box, one environment setting per argument (knobs are read once per process):
-#   bash tools/ab.sh [-w <workload>] "X=1" "IVFHNSW_WALK_OCC=5 IVFHNSW_WALK_SLOTS=5120" ...
+#   bash tools/ab.sh [-w <workload>] "X=1" "IVFHNSW_WALK_MERGE=0" ...
 # Prints queries/s and the per-stage milliseconds of each run.
 cd "$(dirname "$0")/.."
 W=""
