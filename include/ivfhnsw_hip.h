@@ -266,6 +266,23 @@ int ivfhnsw_gpu_pq_train(ivfhnsw_gpu *h, size_t n, size_t d, size_t M, const flo
                          uint8_t *out_assign);
 int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const float *Y, float *C);
 
+/* ---- exact nearest-neighbour tables ------------------------------------------------------------
+ *
+ * ivfhnsw_gpu_knn: for each of nq query rows the k nearest of nx base rows by brute force on the matrix cores -- the exact
+ * form of what the reference's construction side approximates with graph searches (a new node's link candidates,
+ * hnswlib/hnswalg.cpp:112-225; the nsubc + 1 nearest centroids of a centroid, IndexIVF_HNSW_Grouping.cpp:47-62) and of
+ * the ground-truth files its drivers score Recall@1 against (tests/test_ivfhnsw_sift1b.cpp:173-215).  Host pointers;
+ * queries == NULL means the base rows themselves, each row's own entry left out (a neighbour table).  d a multiple of 4,
+ * at most 128; k <= 80.  Arithmetic: dist = (norm(q) + norm(x)) - 2 * dot(q, x) with norm and dot as fmaf chains over
+ * k = 0..d-1 (what v_mfma_f32_32x32x2_f32 computes); results ascending by (dist, id), slots beyond the rows that
+ * exist hold 0xffffffff / FLT_MAX.  out_dists may be NULL.
+ * ivfhnsw_gpu_knn_dev: the same on device pointers, asynchronous on the handle's stream (d_queries may equal d_base:
+ * pass exclude_self = 1 to leave out row i's own entry). */
+int ivfhnsw_gpu_knn(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k,
+                    uint32_t *out_ids, float *out_dists);
+int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *d_queries, const float *d_base,
+                        size_t k, int exclude_self, uint32_t *d_out_ids, float *d_out_dists);
+
 enum ivfhnsw_stage {
     IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */
     IVFHNSW_STAGE_COARSE = 1, /* quantizer->searchKnn, :248 */

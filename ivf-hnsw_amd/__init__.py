@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
     "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
-    "ivfhnsw_gpu_device_count",
+    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev",
 )
 
 
@@ -107,6 +107,10 @@ def lib():
         L.ivfhnsw_gpu_pq_train.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_xty.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_knn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_knn_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_int, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_set_batch_split.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
@@ -344,6 +348,23 @@ class GpuIndex:
         out = np.empty((d, d), np.float32)
         _check(lib().ivfhnsw_gpu_xty(self._h, n, d, _ptr(X), _ptr(Y), _ptr(out)))
         return out
+
+    def knn(self, base, k, queries=None):
+        """Exact k nearest base rows of every query row (ivfhnsw_gpu_knn; queries=None: of every base row, itself left
+        out): (ids u32 [nq, k], dists f32 [nq, k]) ascending by (dist, id)."""
+        x = _np(base, np.float32)
+        nx, d = x.shape
+        q = None if queries is None else _np(queries, np.float32).reshape(-1, d)
+        nq = nx if q is None else q.shape[0]
+        ids = np.empty((nq, k), np.uint32)
+        dist = np.empty((nq, k), np.float32)
+        _check(lib().ivfhnsw_gpu_knn(self._h, nq, nx, d, _ptr(q), _ptr(x), k, _ptr(ids), _ptr(dist)))
+        return ids, dist
+
+    def knn_dev(self, nq, nx, d, d_queries, d_base, k, d_ids, d_dists=None, exclude_self=False):
+        """The same on device buffers (torch CUDA tensors), asynchronous on the handle's stream."""
+        _check(lib().ivfhnsw_gpu_knn_dev(self._h, nq, nx, d, _devptr(d_queries), _devptr(d_base), k, 1 if exclude_self else 0,
+                                         _devptr(d_ids), _devptr(d_dists)))
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

@@ -119,6 +119,7 @@ struct ivfhnsw_gpu {
     // construction side: code books for ivfhnsw_gpu_encode and its workspace
     DevBuf e_pqc, e_ntab, e_a, e_at, e_x, e_idx, e_dist, e_res, e_tmp, e_codes, e_ncodes;
     DevBuf t_x, t_y, t_cb, t_assign, t_part, t_c; // training (pq_train, xty)
+    DevBuf k_q, k_x, k_qn, k_xn, k_part, k_ids, k_dists; // exact neighbour tables (ivfhnsw_gpu_knn)
     DevBuf cg_q, cg_cidx, cg_ids, cg_dists, gc_nn, cg_cvn, cg_tab, cg_tab2, cg_off, cg_alpha2, cg_sub; // add_group
     size_t e_d = 0, e_M = 0;
     bool e_opq = false, has_codebooks = false;
@@ -337,7 +338,7 @@ extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
 
-int ivfhnsw_gpu_abi_version(void) { return 8; }
+int ivfhnsw_gpu_abi_version(void) { return 9; }
 
 int ivfhnsw_gpu_device_count(int *count)
 {
@@ -1184,6 +1185,69 @@ int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const fl
                        (int)d));
     HIP_TRY(hipMemcpyAsync(C, h->t_c.p, d * d * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *d_queries, const float *d_base,
+                        size_t k, int exclude_self, uint32_t *d_out_ids, float *d_out_dists)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (d < 4 || d > 128 || (d & 3))
+        return fail(IVFHNSW_ERR_INVALID, "knn: d %zu must be a multiple of 4, at most 128", d);
+    if (k == 0 || k > 80)
+        return fail(IVFHNSW_ERR_INVALID, "knn: k %zu outside 1..80", k);
+    if (nq > 0x7fffffffull || nx > 0xffffffffull)
+        return fail(IVFHNSW_ERR_INVALID, "knn: too many rows");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!d_queries || !d_base || !d_out_ids)
+        return fail(IVFHNSW_ERR_INVALID, "knn: null buffer");
+    const int nsplit = knn_splits_for(nq, nx ? nx : 1);
+    if ((rc = h->k_qn.ensure(nq * sizeof(float))) || (rc = h->k_xn.ensure((nx ? nx : 1) * sizeof(float))) ||
+        (rc = h->k_part.ensure((size_t)nsplit * nq * k * sizeof(uint64_t))))
+        return rc;
+    float *dd = d_out_dists;
+    if (!dd) {
+        if ((rc = h->k_dists.ensure(nq * k * sizeof(float))))
+            return rc;
+        dd = h->k_dists.as<float>();
+    }
+    HIP_TRY(launch_knn_norms(h->stream, d_queries, h->k_qn.as<float>(), nq, (int)d));
+    HIP_TRY(launch_knn_norms(h->stream, d_base, h->k_xn.as<float>(), nx, (int)d));
+    HIP_TRY(launch_knn(h->stream, d_queries, d_base, h->k_qn.as<float>(), h->k_xn.as<float>(), nq, nx, (int)d, (int)k,
+                       exclude_self ? 0ll : -(1ll << 62), nsplit, h->k_part.as<unsigned long long>(), d_out_ids, dd));
+    return IVFHNSW_OK;
+}
+
+int ivfhnsw_gpu_knn(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k,
+                    uint32_t *out_ids, float *out_dists)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (!base || !out_ids)
+        return fail(IVFHNSW_ERR_INVALID, "knn: null buffer");
+    const bool self = queries == nullptr;
+    if (self)
+        nq = nx;
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if ((rc = upload(h->k_x, base, nx * d * sizeof(float))))
+        return rc;
+    if (!self && (rc = upload(h->k_q, queries, nq * d * sizeof(float))))
+        return rc;
+    if ((rc = h->k_ids.ensure(nq * k * sizeof(uint32_t))) || (rc = h->k_dists.ensure(nq * k * sizeof(float))))
+        return rc;
+    // (k_dists doubles as the output buffer here: knn_dev is handed it explicitly, so it does not allocate its own)
+    if ((rc = ivfhnsw_gpu_knn_dev(h, nq, nx, d, self ? h->k_x.as<float>() : h->k_q.as<float>(), h->k_x.as<float>(), k,
+                                  self ? 1 : 0, h->k_ids.as<uint32_t>(), h->k_dists.as<float>())))
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out_ids, h->k_ids.p, nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (out_dists)
+        HIP_TRY(hipMemcpy(out_dists, h->k_dists.p, nq * k * sizeof(float), hipMemcpyDeviceToHost));
     return IVFHNSW_OK;
 }
 

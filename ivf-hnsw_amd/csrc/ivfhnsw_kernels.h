@@ -193,6 +193,11 @@ hipError_t launch_norm_codes(hipStream_t s, const float *rec, const float *ntab,
 constexpr int kXtyChunk = 2048;
 hipError_t launch_lloyd_update(hipStream_t s, const float *x, const uint8_t *assign, float *cb, size_t n, int d, int M);
 hipError_t launch_xty(hipStream_t s, const float *X, const float *Y, float *partials, float *C, size_t n, int d);
+// exact k-nearest-neighbour tables on the matrix cores (kernels_knn.hip); part = [nsplit][nq][k] u64 workspace
+int knn_splits_for(size_t nq, size_t nx);
+hipError_t launch_knn_norms(hipStream_t s, const float *x, float *out, size_t n, int d);
+hipError_t launch_knn(hipStream_t s, const float *Q, const float *X, const float *qn, const float *xn, size_t nq, size_t nx,
+                      int d, int k, long long self_offset, int nsplit, unsigned long long *part, uint32_t *ids, float *dists);
 // Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-157)
 hipError_t launch_group_table(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
                               const uint32_t *nn, const float *alphas, const float *cv_in, float *out, size_t ngroups,

@@ -1410,3 +1410,65 @@ void orc_index_free_lists(orc_index *ix)
     ix->centroid_norms = ix->alphas = ix->inter_centroid_dists = NULL;
     ix->nn_centroid_idxs = ix->subgroup_sizes = NULL;
 }
+
+/* =============================================================================================
+ * exact k-nearest-neighbour tables (the contract of ivfhnsw_gpu_knn, kernels_knn.hip): NOT a reference
+ * function -- the exact form of what hnswalg.cpp:112-225 and IndexIVF_HNSW_Grouping.cpp:47-62 approximate
+ * with graph searches, and of the drivers' ground-truth files.  norm and dot are fmaf chains over
+ * k = 0..d-1 (the order v_mfma_f32_32x32x2_f32 accumulates in), dist = (norm(q) + norm(x)) - 2 * dot.
+ * queries == NULL: the base rows themselves, own entry left out.  ids / dists: [nq][k] ascending by
+ * (dist, id); missing slots 0xffffffff / FLT_MAX.
+ * ============================================================================================= */
+void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, uint32_t *ids,
+             float *dists)
+{
+    const int self = queries == NULL;
+    if (self) {
+        queries = base;
+        nq = nx;
+    }
+    float *xn = (float *)malloc((nx ? nx : 1) * sizeof(float));
+    for (size_t i = 0; i < nx; i++) {
+        float acc = 0.f;
+        for (size_t kk = 0; kk < d; kk++)
+            acc = fmaf(base[i * d + kk], base[i * d + kk], acc);
+        xn[i] = acc;
+    }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long q = 0; q < (long)nq; q++) {
+        const float *qv = queries + (size_t)q * d;
+        float qn = 0.f;
+        for (size_t kk = 0; kk < d; kk++)
+            qn = fmaf(qv[kk], qv[kk], qn);
+        uint32_t *oi = ids + (size_t)q * k;
+        float *od = dists + (size_t)q * k;
+        size_t have = 0;
+        for (size_t i = 0; i < nx; i++) {
+            if (self && i == (size_t)q)
+                continue;
+            float dot = 0.f;
+            for (size_t kk = 0; kk < d; kk++)
+                dot = fmaf(qv[kk], base[i * d + kk], dot);
+            float t = qn + xn[i];
+            float dist = t - 2.0f * dot;
+            /* insertion into the ascending (dist, id) list; ids arrive ascending, so strict '<' keeps the earlier id */
+            if (have == k && !(dist < od[k - 1]))
+                continue;
+            size_t pos = have < k ? have : k - 1;
+            while (pos > 0 && dist < od[pos - 1]) {
+                od[pos] = od[pos - 1];
+                oi[pos] = oi[pos - 1];
+                pos--;
+            }
+            od[pos] = dist;
+            oi[pos] = (uint32_t)i;
+            if (have < k)
+                have++;
+        }
+        for (size_t j = have; j < k; j++) {
+            oi[j] = 0xffffffffu;
+            od[j] = FLT_MAX;
+        }
+    }
+    free(xn);
+}

@@ -173,6 +173,10 @@ int orc_index_write(const orc_index *ix, const char *path, int grouping);
 int orc_index_read(orc_index *ix, const char *path, int grouping);
 void orc_index_free_lists(orc_index *ix);
 
+/* exact k-nearest-neighbour tables: the contract of ivfhnsw_gpu_knn (see the .c file) */
+void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, uint32_t *ids,
+             float *dists);
+
 #ifdef __cplusplus
 }
 #endif

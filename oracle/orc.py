@@ -85,6 +85,7 @@ def lib():
         L.orc_add_group_encode.restype = C.c_int
         L.orc_pq_lloyd.argtypes = [sz, sz, sz, vp, sz, vp, vp]
         L.orc_xty.argtypes = [sz, sz, vp, vp, sz, vp]
+        L.orc_knn.argtypes = [sz, sz, sz, vp, vp, sz, vp, vp]
         L.orc_compute_centroid_norms.argtypes = [vp, vp]
         L.orc_compute_inter_centroid_dists.argtypes = [vp, sz, vp, vp]
         L.orc_rotate_quantizer.argtypes = [vp, vp]
@@ -145,6 +146,18 @@ def xty(X, Y, chunk):
     C_ = np.empty((d, d), np.float32)
     lib().orc_xty(n, d, _p(X), _p(Y), chunk, _p(C_))
     return C_
+
+
+def knn(base, k, queries=None):
+    """The contract of ivfhnsw_gpu_knn: (ids [nq, k], dists [nq, k]) ascending by (dist, id)."""
+    x = np.ascontiguousarray(base, np.float32)
+    nx, d = x.shape
+    q = None if queries is None else np.ascontiguousarray(queries, np.float32).reshape(-1, d)
+    nq = nx if q is None else len(q)
+    ids = np.empty((nq, k), np.uint32)
+    dist = np.empty((nq, k), np.float32)
+    lib().orc_knn(nq, nx, d, _p(q), _p(x), k, _p(ids), _p(dist))
+    return ids, dist
 
 
 class Hnsw:

@@ -235,26 +235,28 @@ def synthetic_codes(seed, offsets, code_size):
     return ids, codes, norm_codes
 
 
-def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=4096):
+def knn_table(x, k, device=None):
+    """ids of the k nearest OTHER rows of every row of x, ascending (distance, id): the library's exact neighbour
+    table on the matrix cores (ivfhnsw_gpu_knn, kernels_knn.hip; tests/test_gpu_knn.py pins it to the oracle).
+    Rounds 1-2 used torch's GEMM + top-k here; nothing of the corpus preparation runs on torch kernels any more."""
+    import __graft_entry__ as ge
+    g = ge.load_pkg().GpuIndex(getattr(device, "index", None) or 0)   # a torch.device, or None = GPU 0
+    try:
+        ids, _ = g.knn(np.ascontiguousarray(x, np.float32), k)
+    finally:
+        g.close()
+    return ids
+
+
+def knn_graph(centroids, M=16, maxM=32, device=None, chunk=None):
     """A navigable small-world graph for throughput runs: each node links to its M nearest neighbours, then
     reverse links are added up to maxM (the same degree bounds the reference's construction keeps,
     IndexIVF_HNSW.cpp:50, hnswalg.cpp:171-184).  The reference-identical serial construction (orc.Hnsw.build,
     used by every parity test) would take minutes at 10^5-10^6 nodes; graph construction is outside the
-    search path so the throughput corpus uses this brute-force stand-in.  Returns
-    (counts u8 [n], links u32 [n, maxM])."""
-    import torch
-
-    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-    x = torch.from_numpy(np.ascontiguousarray(centroids, np.float32)).to(dev)
-    n = x.shape[0]
-    sq = (x * x).sum(1)
-    knn = torch.empty((n, M), dtype=torch.int64, device=dev)
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        dist = sq[s:e, None] - 2.0 * (x[s:e] @ x.T) + sq[None, :]
-        dist[torch.arange(e - s, device=dev), torch.arange(s, e, device=dev)] = float("inf")
-        knn[s:e] = dist.topk(M, dim=1, largest=False).indices
-    knn = knn.cpu().numpy().astype(np.uint32)
+    search path so the throughput corpus uses this brute-force stand-in: the exact M-NN table from
+    the library's MFMA kernel, the reverse links on the host.  Returns (counts u8 [n], links u32 [n, maxM])."""
+    n = len(centroids)
+    knn = knn_table(centroids, M, device)
     links = np.zeros((n, maxM), np.uint32)
     links[:, :M] = knn
     counts = np.full(n, M, np.int64)
@@ -277,6 +279,9 @@ def knn_graph_torch(centroids, M=16, maxM=32, device=None, chunk=4096):
         links[tgt[ok], slot[ok]] = srcs[ok]
         np.add.at(counts, tgt[ok], 1)
     return counts.astype(np.uint8), links
+
+
+knn_graph_torch = knn_graph   # the name rounds 1-2 used (callers in tests/ and tools/)
 
 
 def synthetic_codes_shard(seed, offsets, code_size, rank, world, list_owner=None):
@@ -337,21 +342,9 @@ def synthetic_codes_sparse(seed, offsets, code_size, lists=None, into=None):
     return into
 
 
-def knn_ids_torch(centroids, k, device=None, chunk=4096):
-    """ids of the k nearest OTHER centroids of every centroid, ascending distance (brute force on the GPU)."""
-    import torch
-
-    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-    x = torch.from_numpy(np.ascontiguousarray(centroids, np.float32)).to(dev)
-    n = x.shape[0]
-    sq = (x * x).sum(1)
-    out = torch.empty((n, k), dtype=torch.int64, device=dev)
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        dist = sq[s:e, None] - 2.0 * (x[s:e] @ x.T) + sq[None, :]
-        dist[torch.arange(e - s, device=dev), torch.arange(s, e, device=dev)] = float("inf")
-        out[s:e] = dist.topk(k, dim=1, largest=False).indices
-    return out.cpu().numpy().astype(np.uint32)
+def knn_ids_torch(centroids, k, device=None, chunk=None):
+    """ids of the k nearest OTHER centroids of every centroid, ascending distance (the library's exact table)."""
+    return knn_table(centroids, k, device)
 
 
 def make_grouping_tables(seed, tb, nsubc, device=None):

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_is_built_and_loads(pkg):
     assert os.path.exists(pkg.LIB_PATH), "run __graft_entry__.build()"
     lib = pkg.lib()
-    assert lib.ivfhnsw_gpu_abi_version() == 8
+    assert lib.ivfhnsw_gpu_abi_version() == 9
 
 
 def test_every_declared_symbol_is_exported(pkg):
