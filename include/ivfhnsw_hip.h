@@ -266,22 +266,41 @@ int ivfhnsw_gpu_pq_train(ivfhnsw_gpu *h, size_t n, size_t d, size_t M, const flo
                          uint8_t *out_assign);
 int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const float *Y, float *C);
 
-/* ---- exact nearest-neighbour tables ------------------------------------------------------------
+/* ---- exact nearest-neighbour tables and graph construction -------------------------------------
  *
  * ivfhnsw_gpu_knn: for each of nq query rows the k nearest of nx base rows by brute force on the matrix cores -- the exact
  * form of what the reference's construction side approximates with graph searches (a new node's link candidates,
- * hnswlib/hnswalg.cpp:112-225; the nsubc + 1 nearest centroids of a centroid, IndexIVF_HNSW_Grouping.cpp:47-62) and of
- * the ground-truth files its drivers score Recall@1 against (tests/test_ivfhnsw_sift1b.cpp:173-215).  Host pointers;
- * queries == NULL means the base rows themselves, each row's own entry left out (a neighbour table).  d a multiple of 4,
- * at most 128; k <= 80.  Arithmetic: dist = (norm(q) + norm(x)) - 2 * dot(q, x) with norm and dot as fmaf chains over
- * k = 0..d-1 (what v_mfma_f32_32x32x2_f32 computes); results ascending by (dist, id), slots beyond the rows that
- * exist hold 0xffffffff / FLT_MAX.  out_dists may be NULL.
- * ivfhnsw_gpu_knn_dev: the same on device pointers, asynchronous on the handle's stream (d_queries may equal d_base:
- * pass exclude_self = 1 to leave out row i's own entry). */
+ * hnswlib/hnswalg.cpp:212-225 -> :48-109; the nsubc + 1 nearest centroids of a centroid,
+ * IndexIVF_HNSW_Grouping.cpp:47-62) and of the ground-truth files its drivers score Recall@1 against
+ * (tests/test_ivfhnsw_sift1b.cpp:173-215).  Host pointers; queries == NULL means the base rows themselves (nq = nx).
+ * mode: IVFHNSW_KNN_ALL every base row is a candidate; IVFHNSW_KNN_NOT_SELF row i of the base is no candidate of query
+ * i (a neighbour table); IVFHNSW_KNN_EARLIER only base rows j < i are candidates of query i (the table an incremental
+ * construction sees: node i against the nodes inserted before it).  d a multiple of 4, at most 128; k <= 80.
+ * Arithmetic: dist = (norm(q) + norm(x)) - 2 * dot(q, x) with norm and dot as fmaf chains over k = 0..d-1 (what
+ * v_mfma_f32_32x32x2_f32 computes); results ascending by (dist, id), slots beyond the candidates that exist hold
+ * 0xffffffff / FLT_MAX.  out_dists may be NULL.
+ * ivfhnsw_gpu_knn_dev: the same on device pointers, asynchronous on the handle's stream (d_queries may equal d_base). */
+#define IVFHNSW_KNN_ALL 0
+#define IVFHNSW_KNN_NOT_SELF 1
+#define IVFHNSW_KNN_EARLIER 2
 int ivfhnsw_gpu_knn(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k,
-                    uint32_t *out_ids, float *out_dists);
+                    int mode, uint32_t *out_ids, float *out_dists);
 int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *d_queries, const float *d_base,
-                        size_t k, int exclude_self, uint32_t *d_out_ids, float *d_out_dists);
+                        size_t k, int mode, uint32_t *d_out_ids, float *d_out_dists);
+
+/* ivfhnsw_gpu_build_graph: hnswlib::HierarchicalNSW::addPoint for ALL n nodes at once (hnswlib/hnswalg.cpp:212-225 as
+ * IndexIVF_HNSW::build_quantizer loops it, IndexIVF_HNSW.cpp:34-66), with ONE deviation: a node's link candidates are
+ * its EXACT ncand nearest among the nodes inserted before it (ivfhnsw_gpu_knn, IVFHNSW_KNN_EARLIER, on the matrix cores)
+ * instead of the efConstruction results of a greedy search of the graph built so far (hnswalg.cpp:221 -> :48-109).
+ * Everything after the candidates is the reference's: getNeighborsByHeuristic down to M links (:110-146, distances by
+ * fstdistfunc, :326-357), the links stored farthest first (:153-170), and mutuallyConnectNewElement's reverse links in
+ * insertion order -- appended while the neighbour has room, else the neighbour's maxM + 1 candidates shrunk by the same
+ * heuristic (:171-209).  Because the candidates no longer depend on the graph, node t's final list is a fold over the
+ * later nodes that chose t, in their order: every node is processed independently (host threads), and the result is
+ * exactly what the serial loop would leave.  vectors [n][d] host; out_counts [n] (the 1-byte link count of
+ * hnswalg.cpp:25); out_links [n][maxM].  M <= maxM <= 64, ncand <= 80, n < 2^32. */
+int ivfhnsw_gpu_build_graph(ivfhnsw_gpu *h, size_t n, size_t d, const float *vectors, size_t M, size_t maxM, size_t ncand,
+                            uint8_t *out_counts, uint32_t *out_links);
 
 enum ivfhnsw_stage {
     IVFHNSW_STAGE_OPQ = 0,    /* opq_matrix->apply, IndexIVF_HNSW.cpp:240 */

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
     "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
-    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev",
+    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph",
 )
 
 
@@ -108,7 +108,9 @@ def lib():
                                            C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_xty.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_knn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
-                                      C.c_void_p, C.c_void_p]
+                                      C.c_int, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_build_graph.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                              C.c_size_t, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_knn_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_int, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
@@ -349,22 +351,39 @@ class GpuIndex:
         _check(lib().ivfhnsw_gpu_xty(self._h, n, d, _ptr(X), _ptr(Y), _ptr(out)))
         return out
 
-    def knn(self, base, k, queries=None):
-        """Exact k nearest base rows of every query row (ivfhnsw_gpu_knn; queries=None: of every base row, itself left
-        out): (ids u32 [nq, k], dists f32 [nq, k]) ascending by (dist, id)."""
+    KNN_ALL, KNN_NOT_SELF, KNN_EARLIER = 0, 1, 2
+
+    def knn(self, base, k, queries=None, mode=None):
+        """Exact k nearest base rows of every query row (ivfhnsw_gpu_knn; queries=None: of every base row, by default
+        itself left out; mode KNN_EARLIER: only rows before it): (ids u32 [nq, k], dists f32 [nq, k]) ascending by
+        (dist, id)."""
+        if mode is None:
+            mode = self.KNN_NOT_SELF if queries is None else self.KNN_ALL
         x = _np(base, np.float32)
         nx, d = x.shape
         q = None if queries is None else _np(queries, np.float32).reshape(-1, d)
         nq = nx if q is None else q.shape[0]
         ids = np.empty((nq, k), np.uint32)
         dist = np.empty((nq, k), np.float32)
-        _check(lib().ivfhnsw_gpu_knn(self._h, nq, nx, d, _ptr(q), _ptr(x), k, _ptr(ids), _ptr(dist)))
+        _check(lib().ivfhnsw_gpu_knn(self._h, nq, nx, d, _ptr(q), _ptr(x), k, mode, _ptr(ids), _ptr(dist)))
         return ids, dist
 
-    def knn_dev(self, nq, nx, d, d_queries, d_base, k, d_ids, d_dists=None, exclude_self=False):
+    def knn_dev(self, nq, nx, d, d_queries, d_base, k, d_ids, d_dists=None, exclude_self=False, mode=None):
         """The same on device buffers (torch CUDA tensors), asynchronous on the handle's stream."""
-        _check(lib().ivfhnsw_gpu_knn_dev(self._h, nq, nx, d, _devptr(d_queries), _devptr(d_base), k, 1 if exclude_self else 0,
+        if mode is None:
+            mode = self.KNN_NOT_SELF if exclude_self else self.KNN_ALL
+        _check(lib().ivfhnsw_gpu_knn_dev(self._h, nq, nx, d, _devptr(d_queries), _devptr(d_base), k, mode,
                                          _devptr(d_ids), _devptr(d_dists)))
+
+    def build_graph(self, vectors, M=16, maxM=32, ncand=64):
+        """hnswlib's addPoint loop for all nodes at once, candidates = the exact ncand nearest earlier nodes
+        (ivfhnsw_gpu_build_graph): (counts u8 [n], links u32 [n, maxM])."""
+        v = _np(vectors, np.float32)
+        n, d = v.shape
+        counts = np.zeros(n, np.uint8)
+        links = np.zeros((n, maxM), np.uint32)
+        _check(lib().ivfhnsw_gpu_build_graph(self._h, n, d, _ptr(v), M, maxM, ncand, _ptr(counts), _ptr(links)))
+        return counts, links
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

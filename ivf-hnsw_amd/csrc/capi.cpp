@@ -334,6 +334,9 @@ int upload_tables(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, std::vector<uint32_
 
 } // namespace
 
+// for the library's other translation units (graph_build.cpp): record a failure the way every entry point does
+int ivfhnsw_gpu_fail_msg(int code, const char *msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 const char *ivfhnsw_gpu_last_error(void) { return g_last_error.c_str(); }
@@ -1189,7 +1192,7 @@ int ivfhnsw_gpu_xty(ivfhnsw_gpu *h, size_t n, size_t d, const float *X, const fl
 }
 
 int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *d_queries, const float *d_base,
-                        size_t k, int exclude_self, uint32_t *d_out_ids, float *d_out_dists)
+                        size_t k, int mode, uint32_t *d_out_ids, float *d_out_dists)
 {
     int rc = bind(h);
     if (rc)
@@ -1200,11 +1203,14 @@ int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const fl
         return fail(IVFHNSW_ERR_INVALID, "knn: k %zu outside 1..80", k);
     if (nq > 0x7fffffffull || nx > 0xffffffffull)
         return fail(IVFHNSW_ERR_INVALID, "knn: too many rows");
+    if (mode < IVFHNSW_KNN_ALL || mode > IVFHNSW_KNN_EARLIER)
+        return fail(IVFHNSW_ERR_INVALID, "knn: unknown mode %d", mode);
     if (nq == 0)
         return IVFHNSW_OK;
     if (!d_queries || !d_base || !d_out_ids)
         return fail(IVFHNSW_ERR_INVALID, "knn: null buffer");
-    const int nsplit = knn_splits_for(nq, nx ? nx : 1);
+    // (the triangular table is one sweep per row block: its column range depends on the block)
+    const int nsplit = mode == IVFHNSW_KNN_EARLIER ? 1 : knn_splits_for(nq, nx ? nx : 1);
     if ((rc = h->k_qn.ensure(nq * sizeof(float))) || (rc = h->k_xn.ensure((nx ? nx : 1) * sizeof(float))) ||
         (rc = h->k_part.ensure((size_t)nsplit * nq * k * sizeof(uint64_t))))
         return rc;
@@ -1217,12 +1223,12 @@ int ivfhnsw_gpu_knn_dev(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const fl
     HIP_TRY(launch_knn_norms(h->stream, d_queries, h->k_qn.as<float>(), nq, (int)d));
     HIP_TRY(launch_knn_norms(h->stream, d_base, h->k_xn.as<float>(), nx, (int)d));
     HIP_TRY(launch_knn(h->stream, d_queries, d_base, h->k_qn.as<float>(), h->k_xn.as<float>(), nq, nx, (int)d, (int)k,
-                       exclude_self ? 0ll : -(1ll << 62), nsplit, h->k_part.as<unsigned long long>(), d_out_ids, dd));
+                       mode, nsplit, h->k_part.as<unsigned long long>(), d_out_ids, dd));
     return IVFHNSW_OK;
 }
 
 int ivfhnsw_gpu_knn(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k,
-                    uint32_t *out_ids, float *out_dists)
+                    int mode, uint32_t *out_ids, float *out_dists)
 {
     int rc = bind(h);
     if (rc)
@@ -1242,7 +1248,7 @@ int ivfhnsw_gpu_knn(ivfhnsw_gpu *h, size_t nq, size_t nx, size_t d, const float 
         return rc;
     // (k_dists doubles as the output buffer here: knn_dev is handed it explicitly, so it does not allocate its own)
     if ((rc = ivfhnsw_gpu_knn_dev(h, nq, nx, d, self ? h->k_x.as<float>() : h->k_q.as<float>(), h->k_x.as<float>(), k,
-                                  self ? 1 : 0, h->k_ids.as<uint32_t>(), h->k_dists.as<float>())))
+                                  mode, h->k_ids.as<uint32_t>(), h->k_dists.as<float>())))
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out_ids, h->k_ids.p, nq * k * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -197,7 +197,7 @@ hipError_t launch_xty(hipStream_t s, const float *X, const float *Y, float *part
 int knn_splits_for(size_t nq, size_t nx);
 hipError_t launch_knn_norms(hipStream_t s, const float *x, float *out, size_t n, int d);
 hipError_t launch_knn(hipStream_t s, const float *Q, const float *X, const float *qn, const float *xn, size_t nq, size_t nx,
-                      int d, int k, long long self_offset, int nsplit, unsigned long long *part, uint32_t *ids, float *dists);
+                      int d, int k, int mode, int nsplit, unsigned long long *part, uint32_t *ids, float *dists); // mode: IVFHNSW_KNN_*
 // Grouping construction (IndexIVF_HNSW_Grouping.cpp:43-157)
 hipError_t launch_group_table(hipStream_t s, int mode, const float *vectors, const uint32_t *centroid_idx,
                               const uint32_t *nn, const float *alphas, const float *cv_in, float *out, size_t ngroups,

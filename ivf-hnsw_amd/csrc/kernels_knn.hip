@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float *__restrict_
 template <int D2, int CAP>
 __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restrict__ Q, const float *__restrict__ X,
                                                           const float *__restrict__ qn, const float *__restrict__ xn,
-                                                          int nq, size_t nx, int d, int k, long long self_offset,
+                                                          int nq, size_t nx, int d, int k, int mode,
                                                           size_t cols_per_split,
                                                           unsigned long long *__restrict__ out_keys)
 {
@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     const int m = lane & 31, kk = lane >> 5;
     const int r0 = blockIdx.x * 128 + wave * 32;
     const size_t c_begin = (size_t)blockIdx.y * cols_per_split;
-    const size_t c_end = c_begin + cols_per_split < nx ? c_begin + cols_per_split : nx;
+    size_t c_end = c_begin + cols_per_split < nx ? c_begin + cols_per_split : nx;
+    // mode 2 (only EARLIER rows are candidates: the neighbour table of an incremental construction, row i against
+    // rows 0..i-1): columns at and beyond the block's last row are never candidates
+    if (mode == 2 && c_end > (size_t)(blockIdx.x + 1) * 128)
+        c_end = (size_t)(blockIdx.x + 1) * 128;
     unsigned long long *buf = s_buf + (size_t)wave * 32 * CAP;
     uint32_t *cnt = s_cnt + wave * 32;
     float *thr_s = s_thr + wave * 32;
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         for (int r = 0; r < 16; r++) {
             const float dist = __fsub_rn(__fadd_rn(qn_r[r], xnc), __fmul_rn(2.0f, acc[r]));
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-            const bool pass = col_ok && dist < thr[r] && (long long)col != (long long)(r0 + row) + self_offset;
+            const bool pass = col_ok && dist < thr[r] && (mode == 0 || (mode == 1 ? (long long)col != (long long)(r0 + row)
+                                                                                   : (long long)col < (long long)(r0 + row)));
             const unsigned long long mask = __ballot(pass);
             if (mask) { // wave-uniform: rare once the thresholds have settled
                 const uint32_t half = kk ? (uint32_t)(mask >> 32) : (uint32_t)mask;
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(64) void knn_merge_kernel(const unsigned long long 
 
 template <int D2, int CAP>
 hipError_t launch_knn_t(hipStream_t s, const float *Q, const float *X, const float *qn, const float *xn, int nq, size_t nx,
-                        int d, int k, long long self_offset, int nsplit, size_t cols_per_split, unsigned long long *part)
+                        int d, int k, int mode, int nsplit, size_t cols_per_split, unsigned long long *part)
 {
     const size_t shm = (size_t)(2 * D2 * 32 + 32) * sizeof(float) + (size_t)4 * 32 * CAP * sizeof(unsigned long long) +
                        128 * sizeof(uint32_t) + 128 * sizeof(float);
@@ -297,7 +302,7 @@ hipError_t launch_knn_t(hipStream_t s, const float *Q, const float *X, const flo
     if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr_set); e != hipSuccess)
         return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((nq + 127) / 128), (unsigned)nsplit), dim3(256), shm, s, Q, X, qn, xn, nq, nx, d,
-                       k, self_offset, cols_per_split, part);
+                       k, mode, cols_per_split, part);
     return hipGetLastError();
 }
 
@@ -324,20 +329,20 @@ hipError_t launch_knn_norms(hipStream_t s, const float *x, float *out, size_t n,
 
 // part: [nsplit][nq][k] u64 workspace
 hipError_t launch_knn(hipStream_t s, const float *Q, const float *X, const float *qn, const float *xn, size_t nq, size_t nx,
-                      int d, int k, long long self_offset, int nsplit, unsigned long long *part, uint32_t *ids, float *dists)
+                      int d, int k, int mode, int nsplit, unsigned long long *part, uint32_t *ids, float *dists)
 {
     if (nq == 0 || k == 0)
         return hipSuccess;
-    if (d < 4 || d > 128 || (d & 3) || k > 80 || nq > 0x7fffffffull || nx > 0xffffffffull || nsplit < 1)
+    if (d < 4 || d > 128 || (d & 3) || k > 80 || nq > 0x7fffffffull || nx > 0xffffffffull || nsplit < 1 || mode < 0 || mode > 2)
         return hipErrorInvalidValue;
     size_t cps = (nx + nsplit - 1) / nsplit;
     cps = (cps + 31) & ~(size_t)31;
     hipError_t e;
     const int d2 = (d + 1) / 2;
 #define IVFHNSW_KNN(D2)                                                                                                \
-    (k <= 16   ? launch_knn_t<D2, 48>(s, Q, X, qn, xn, (int)nq, nx, d, k, self_offset, nsplit, cps, part)              \
-     : k <= 32 ? launch_knn_t<D2, 64>(s, Q, X, qn, xn, (int)nq, nx, d, k, self_offset, nsplit, cps, part)              \
-               : launch_knn_t<D2, 112>(s, Q, X, qn, xn, (int)nq, nx, d, k, self_offset, nsplit, cps, part))
+    (k <= 16   ? launch_knn_t<D2, 48>(s, Q, X, qn, xn, (int)nq, nx, d, k, mode, nsplit, cps, part)              \
+     : k <= 32 ? launch_knn_t<D2, 64>(s, Q, X, qn, xn, (int)nq, nx, d, k, mode, nsplit, cps, part)              \
+               : launch_knn_t<D2, 112>(s, Q, X, qn, xn, (int)nq, nx, d, k, mode, nsplit, cps, part))
     if (d2 <= 16)
         e = IVFHNSW_KNN(16);
     else if (d2 <= 32)

@@ -1416,14 +1416,14 @@ void orc_index_free_lists(orc_index *ix)
  * function -- the exact form of what hnswalg.cpp:112-225 and IndexIVF_HNSW_Grouping.cpp:47-62 approximate
  * with graph searches, and of the drivers' ground-truth files.  norm and dot are fmaf chains over
  * k = 0..d-1 (the order v_mfma_f32_32x32x2_f32 accumulates in), dist = (norm(q) + norm(x)) - 2 * dot.
- * queries == NULL: the base rows themselves, own entry left out.  ids / dists: [nq][k] ascending by
- * (dist, id); missing slots 0xffffffff / FLT_MAX.
+ * queries == NULL: the base rows themselves.  ids / dists: [nq][k] ascending by (dist, id); missing
+ * slots 0xffffffff / FLT_MAX.
  * ============================================================================================= */
-void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, uint32_t *ids,
-             float *dists)
+void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, int mode,
+             uint32_t *ids, float *dists)
 {
-    const int self = queries == NULL;
-    if (self) {
+    /* mode: 0 every base row is a candidate, 1 not row q itself, 2 only rows before q (ivfhnsw_hip.h IVFHNSW_KNN_*) */
+    if (queries == NULL) {
         queries = base;
         nq = nx;
     }
@@ -1444,7 +1444,7 @@ void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *
         float *od = dists + (size_t)q * k;
         size_t have = 0;
         for (size_t i = 0; i < nx; i++) {
-            if (self && i == (size_t)q)
+            if ((mode == 1 && i == (size_t)q) || (mode == 2 && i >= (size_t)q))
                 continue;
             float dot = 0.f;
             for (size_t kk = 0; kk < d; kk++)
@@ -1471,4 +1471,33 @@ void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *
         }
     }
     free(xn);
+}
+
+/* The serial loop ivfhnsw_gpu_build_graph unrolls: hnswalg.cpp:212-225 addPoint for c = 0..n-1, where the
+ * candidates handed to mutuallyConnectNewElement are the exact ncand nearest earlier nodes (orc_knn, mode 2)
+ * with their fstdistfunc distances, instead of searchBaseLayer's results.  Everything else is the
+ * reference's construction code above (hnsw_connect). */
+orc_hnsw *orc_hnsw_build_exact(size_t d, size_t n, size_t M, size_t maxM, size_t ncand, const float *vectors)
+{
+    orc_hnsw *g = orc_hnsw_new(d, n, M, maxM, ncand);
+    memcpy(g->vectors, vectors, n * d * sizeof(float));
+    uint32_t *ids = (uint32_t *)malloc((n ? n : 1) * ncand * sizeof(uint32_t));
+    float *dd = (float *)malloc((n ? n : 1) * ncand * sizeof(float));
+    orc_knn(0, n, d, NULL, vectors, ncand, 2, ids, dd);
+    for (size_t c = 0; c < n; c++) {
+        g->n = c + 1;
+        if (c == 0)
+            continue;
+        orc_pq top;
+        pq_init(&top);
+        for (size_t i = 0; i < ncand && ids[c * ncand + i] != 0xffffffffu; i++) {
+            uint32_t t = ids[c * ncand + i];
+            pq_push(&top, orc_l2sqr(vectors + c * d, vectors + (size_t)t * d, d), t);
+        }
+        hnsw_connect(g, (uint32_t)c, &top);
+        pq_free(&top);
+    }
+    free(ids);
+    free(dd);
+    return g;
 }

@@ -174,8 +174,10 @@ int orc_index_read(orc_index *ix, const char *path, int grouping);
 void orc_index_free_lists(orc_index *ix);
 
 /* exact k-nearest-neighbour tables: the contract of ivfhnsw_gpu_knn (see the .c file) */
-void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, uint32_t *ids,
-             float *dists);
+void orc_knn(size_t nq, size_t nx, size_t d, const float *queries, const float *base, size_t k, int mode,
+             uint32_t *ids, float *dists);
+/* the serial insertion loop ivfhnsw_gpu_build_graph unrolls (exact candidates, the reference's connect step) */
+orc_hnsw *orc_hnsw_build_exact(size_t d, size_t n, size_t M, size_t maxM, size_t ncand, const float *vectors);
 
 #ifdef __cplusplus
 }

@@ -85,7 +85,9 @@ def lib():
         L.orc_add_group_encode.restype = C.c_int
         L.orc_pq_lloyd.argtypes = [sz, sz, sz, vp, sz, vp, vp]
         L.orc_xty.argtypes = [sz, sz, vp, vp, sz, vp]
-        L.orc_knn.argtypes = [sz, sz, sz, vp, vp, sz, vp, vp]
+        L.orc_knn.argtypes = [sz, sz, sz, vp, vp, sz, C.c_int, vp, vp]
+        L.orc_hnsw_build_exact.restype = vp
+        L.orc_hnsw_build_exact.argtypes = [sz, sz, sz, sz, sz, vp]
         L.orc_compute_centroid_norms.argtypes = [vp, vp]
         L.orc_compute_inter_centroid_dists.argtypes = [vp, sz, vp, vp]
         L.orc_rotate_quantizer.argtypes = [vp, vp]
@@ -148,15 +150,18 @@ def xty(X, Y, chunk):
     return C_
 
 
-def knn(base, k, queries=None):
-    """The contract of ivfhnsw_gpu_knn: (ids [nq, k], dists [nq, k]) ascending by (dist, id)."""
+def knn(base, k, queries=None, mode=None):
+    """The contract of ivfhnsw_gpu_knn: (ids [nq, k], dists [nq, k]) ascending by (dist, id).  mode 0 all rows,
+    1 not the row itself (default without queries), 2 only earlier rows."""
+    if mode is None:
+        mode = 1 if queries is None else 0
     x = np.ascontiguousarray(base, np.float32)
     nx, d = x.shape
     q = None if queries is None else np.ascontiguousarray(queries, np.float32).reshape(-1, d)
     nq = nx if q is None else len(q)
     ids = np.empty((nq, k), np.uint32)
     dist = np.empty((nq, k), np.float32)
-    lib().orc_knn(nq, nx, d, _p(q), _p(x), k, _p(ids), _p(dist))
+    lib().orc_knn(nq, nx, d, _p(q), _p(x), k, mode, _p(ids), _p(dist))
     return ids, dist
 
 
@@ -178,6 +183,13 @@ class Hnsw:
             rc = lib().orc_hnsw_add_point(g.h, _p(v[i]))
             assert rc == 0
         return g
+
+    @classmethod
+    def build_exact(cls, vectors, M=16, maxM=32, ncand=64):
+        """The serial insertion loop with exact candidates (the contract of ivfhnsw_gpu_build_graph)."""
+        v = np.ascontiguousarray(vectors, np.float32)
+        n, d = v.shape
+        return cls(lib().orc_hnsw_build_exact(d, n, M, maxM, ncand, _p(v)))
 
     @classmethod
     def from_arrays(cls, counts, links, vectors, M, enterpoint=0):
