@@ -67,8 +67,16 @@ WORKLOADS = {
     "synthetic-1B-pq16-nc993127-nprobe32": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
     "synthetic-1B-pq16-nc993127-nprobe64": (1_000_000_000, 993127, 128, 16, 64, 30000, 100, 10000),
     "deep-1B-d96-opq-pq16-nc999973-nprobe128": (1_000_000_000, 999973, 96, 16, 128, 100000, 130, 10000),
+    # the metric's shape on CLUSTERED centroids (tight clusters of ~64, what k-means centroids of real descriptors look
+    # like: a query's nearest centroids are each other's neighbours), same lists, codes and operating point
+    "clustered-1B-pq16-nc993127-nprobe32": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
+    "clustered-grouping-1B-pq16-nc993127-nsubc64-opq-pruning": (1_000_000_000, 993127, 128, 16, 32, 10000, 80, 10000),
+    "clustered-100M-pq16-nc131072-nprobe32": (100_000_000, 1 << 17, 128, 16, 32, 10000, 80, 10000),
 }
-WORKLOAD_FLAGS = {"deep-1B-d96-opq-pq16-nc999973-nprobe128": {"kind": "deep", "opq": True}}
+WORKLOAD_FLAGS = {"deep-1B-d96-opq-pq16-nc999973-nprobe128": {"kind": "deep", "opq": True},
+                  "clustered-1B-pq16-nc993127-nprobe32": {"kind": "clustered"},
+                  "clustered-grouping-1B-pq16-nc993127-nsubc64-opq-pruning": {"kind": "clustered"},
+                  "clustered-100M-pq16-nc131072-nprobe32": {"kind": "clustered"}}
 DEFAULT_WORKLOAD = "synthetic-1B-pq16-nc993127-nprobe32"
 STRONG_BATCH = 80000
 
@@ -88,10 +96,18 @@ class Corpus:
         self.name, self.n_total, self.nc, self.d, self.M, self.seed = name, n_total, nc, d, M, seed
         flags = WORKLOAD_FLAGS.get(name, {})
         self.kind = flags.get("kind", "sift")
-        self.grouping = name.startswith("grouping")
+        self.grouping = "grouping" in name
         t0 = time.time()
         self.tb = tb = synth.make_throughput_tables(seed, nc, d, M, n_total, kind=self.kind)
-        self.counts, self.links = synth.knn_graph_torch(tb["centroids"], 16, 32, device=dev)
+        # the coarse graph: hnswlib's insertion loop with exact candidates on the device (ivfhnsw_gpu_build_graph; M 16,
+        # maxM 32 as IndexIVF_HNSW.cpp:50 builds it), or -- rounds 1-2 -- a plain 16-NN graph with reverse links
+        self.graph_kind = os.environ.get("IVFHNSW_BENCH_GRAPH", "insert")
+        if self.graph_kind == "knn":
+            self.counts, self.links = synth.knn_graph(tb["centroids"], 16, 32, device=dev)
+        else:
+            gb = pkg.GpuIndex(local_rank)
+            self.counts, self.links = gb.build_graph(tb["centroids"], 16, 32, 64)
+            gb.close()
         self.centroid_norms = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
         self.opq_A, self.gt, self.vectors = None, None, tb["centroids"]
         if flags.get("opq") and not self.grouping:
@@ -135,7 +151,7 @@ class Corpus:
         rng = np.random.default_rng(seed)
         # points near centroids, so that walks end in populated regions
         return (self.tb["centroids"][rng.choice(self.nc, nq)]
-                + rng.normal(0, 12.0 if self.kind == "sift" else 0.03, size=(nq, self.d))).astype(np.float32)
+                + rng.normal(0, 0.03 if self.kind == "deep" else 12.0, size=(nq, self.d))).astype(np.float32)
 
     def oracle(self, synth, orc):
         """The CPU port over a full host copy of the device's byte stream (the cpu_baseline / parity leg only)."""
@@ -194,8 +210,10 @@ def scan_roofline(g, M, stage, traffic_gb, steps):
     return {
         "launches_per_step": parts,
         "bound": "hbm", "kernel": g.last_scan_kernel(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_gb,
-        "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/scan_traffic.json)",
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "traffic": None if traffic_gb is None else round(traffic_gb / parts, 4),
+        "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the step's scan launches / launches, "
+                        "profiles/scan_traffic.json)",
         "algorithmic_gb_per_launch": round(bpc * ncodes / 1e9, 4), "bytes_per_code": bpc, "codes_per_launch": int(ncodes),
         "avg_launch_ms": round(avg_ms, 4),
     }
@@ -244,7 +262,8 @@ def main():
                          "serves its own batches, collectives stay inside the group (DESIGN.md 7)")
     ap.add_argument("--no-replica-layout", action="store_true",
                     help="N > 1: skip the extra `replica_groups` measurement (2 groups x N/2 shards on the same ranks)")
-    ap.add_argument("--no-split", action="store_true", help="skip the split_batch measurement (profiling runs: one launch shape per kernel)")
+    ap.add_argument("--no-split", action="store_true", help="run every batch in ONE part (ivfhnsw_gpu_set_batch_split 0): "
+                    "profiling runs that want one launch shape per kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
@@ -337,6 +356,8 @@ def main():
 
     # everything the timed region touches lives in HBM already
     g.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.no_split:
+        g.set_batch_split(0)
     d_q = torch.from_numpy(queries).to(dev)
     d_dist = torch.empty((nq, 1), dtype=torch.float32, device=dev)
     d_lab = torch.empty((nq, 1), dtype=torch.int64, device=dev)
@@ -438,27 +459,37 @@ def main():
             g.search(queries, 1, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         host_qps = 3 * nq / (time.perf_counter() - t_h)
 
-    # The same batch as two uneven parts on two streams INSIDE one call (ivfhnsw_gpu_set_batch_split; reported beside
-    # `value`, never as it: `value` and `roofline` are measured with one launch per kernel).  The second part's walk
-    # fills the tail of the first part's, the first part's scan runs beside it.
-    split = None
-    if world == 1 and nq >= 8192 and not args.no_split:
-        g.set_batch_split(780)
+    # `value` is what a plain search_dev call delivers: since round 3 a batch of >= 8192 queries runs as two uneven parts on
+    # two streams inside the call (ivfhnsw_gpu_set_batch_split, default 780 permille in the first part).  Reported beside
+    # it, never as it: the same batch in ONE part (IVFHNSW_SPLIT=0) -- one launch per kernel, the shape rounds 1-2 measured
+    # and the one the scan's rate reads best on.
+    one_part = None
+    split_active = world == 1 and nq >= 8192 and os.environ.get("IVFHNSW_SPLIT", "") != "0" and not args.no_split
+    if split_active:
+        g.set_batch_split(0)
         sp_d, sp_l = torch.empty_like(d_dist), torch.empty_like(d_lab)
         for _ in range(3):
             g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         torch.cuda.synchronize()
         n_sp = max(args.steps, n_sus // 4)
+        g.set_profiling(2)
+        g.reset_stage_ms()
         t_sp = time.perf_counter()
         for _ in range(n_sp):
             g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
         torch.cuda.synchronize()
         el_sp = time.perf_counter() - t_sp
-        g.set_batch_split(0)
-        split = {"first_part_permille": 780, "steps": n_sp, "queries_per_s": round(nq * n_sp / el_sp, 1),
-                 "ms_per_batch": round(el_sp / n_sp * 1e3, 4),
-                 "results_equal_to_one_part": bool(torch.equal(sp_l, d_lab)) and
-                 bool(torch.equal(sp_d.view(torch.int32), d_dist.view(torch.int32)))}
+        st1 = g.stage_ms()
+        g.set_profiling(False)
+        g.set_batch_split(780)
+        r1 = scan_roofline(g, M, st1, None, n_sp)
+        one_part = {"steps": n_sp, "queries_per_s": round(nq * n_sp / el_sp, 1), "ms_per_batch": round(el_sp / n_sp * 1e3, 4),
+                    "scan_avg_launch_ms": r1["avg_launch_ms"], "scan_gbps": r1["achieved"], "scan_frac_of_hbm_peak": r1["frac"],
+                    "results_equal_to_default": bool(torch.equal(sp_l, d_lab)) and
+                    bool(torch.equal(sp_d.view(torch.int32), d_dist.view(torch.int32)))}
+        # leave the handle as the timed region left it: the last call a two-part one (scan counts, kernel name)
+        g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        torch.cuda.synchronize()
 
     # Serving form (reported beside `value`, never as it): --in-flight batches on as many streams, each on its own
     # view of the index (ivfhnsw_gpu_create_view: same tables, own workspace).  The walk is ALU-bound and ends in a
@@ -558,7 +589,12 @@ def main():
                           "stage bracketed (six event pairs per step cost 2.3 %% of it)" % n_aux,
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
-            "split_batch": split,
+            "batch_split": {"parts": 2 if split_active else 1, "first_part_permille": 780 if split_active else None,
+                            "note": "a plain ivfhnsw_gpu_search_dev call of >= 8192 queries runs as two uneven parts on two "
+                                    "streams (default since ABI 9; IVFHNSW_SPLIT=0 = one part): `value`, `roofline` "
+                                    "(17 B x ALL codes of the step over the SUMMED scan-launch time) and the stage "
+                                    "times are this default path's"},
+            "one_part": one_part,
         }
         if replica is not None:
             out["replica_groups"] = replica
@@ -639,24 +675,22 @@ def main():
             except Exception as e:  # the measuring stick must never fail the bench
                 log("[bench] float_order leg skipped: %r" % (e,))
 
-        # secondary results in the same line: the 1B corpus at configs[2]'s operating point, and configs[1]
+        # secondary results in the same line: configs[2]'s operating point on the same corpus, configs[1], the metric's
+        # shape on CLUSTERED centroids, and a recall-bearing index built by the library's own pipeline
         if single and args.workload == DEFAULT_WORKLOAD and not args.no_secondary:
             out["secondary"] = []
-            sec = [("synthetic-1B-pq16-nc993127-nprobe64", C, ox), ("synthetic-100M-pq16-nc131072-nprobe32", None, None)]
-            for name, CC, oxx in sec:
-                own = CC is None
-                if own:
-                    CC = Corpus(pkg, synth, name, args.seed, dev, local_rank)
-                    CC.g.set_stream(torch.cuda.current_stream().cuda_stream)
-                _, _, _, _, s_np, s_mc, s_ef, s_nq = WORKLOADS[name]
-                sq = queries if not own else CC.queries(s_nq, args.seed + 1)
-                s_dq = torch.from_numpy(sq).to(dev)
+            try:
+                nthr = min(16, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                nthr = 8
+
+            def measure(gg, s_nq, s_dq, s_np, s_mc, s_ef, pruning=False):
+                """(entry, labels, distances) of one workload on handle gg: the default call, every stage bracketed."""
                 s_dd = torch.empty((s_nq, 1), dtype=torch.float32, device=dev)
                 s_ll = torch.empty((s_nq, 1), dtype=torch.int64, device=dev)
-                gg = CC.g
 
                 def s_step():
-                    gg.search_dev(s_nq, 1, s_dq, s_dd, s_ll, s_np, s_mc, efSearch=s_ef)
+                    gg.search_dev(s_nq, 1, s_dq, s_dd, s_ll, s_np, s_mc, efSearch=s_ef, do_pruning=pruning)
 
                 for _ in range(3 + args.warmup):
                     s_step()
@@ -666,28 +700,93 @@ def main():
                 t_s = timed_steps(torch, s_step, torch.cuda.synchronize, args.steps)
                 s_stage = gg.stage_ms()
                 gg.set_profiling(False)
-                ent = {"workload": name, "value": round(s_nq * args.steps / t_s, 1), "unit": "queries/s",
-                       "ms_per_step": round(t_s / args.steps * 1e3, 4), "nprobe": s_np, "max_codes": s_mc,
-                       "efSearch": s_ef, "batch": s_nq,
-                       "roofline": scan_roofline(gg, CC.M, s_stage, pmc_traffic(name)[0], args.steps),
-                       "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in s_stage.items()}}
+                e = {"value": round(s_nq * args.steps / t_s, 1), "unit": "queries/s",
+                     "ms_per_step": round(t_s / args.steps * 1e3, 4), "nprobe": s_np, "max_codes": s_mc, "efSearch": s_ef,
+                     "batch": s_nq, "roofline": scan_roofline(gg, 16, s_stage, None, args.steps),
+                     "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in s_stage.items()}}
+                return e, s_ll.cpu().numpy()[:, 0], s_dd.cpu().numpy()[:, 0]
+
+            def parity_of(r_l, r_d, lg, dg, n_chk):
+                return {"queries_checked": n_chk, "labels_equal": int((r_l[:n_chk, 0] == lg[:n_chk]).sum()),
+                        "distances_bit_equal": int((r_d[:n_chk, 0].view(np.uint32) == dg[:n_chk].view(np.uint32)).sum())}
+
+            # (1) the primary corpus at configs[2]'s point (its host copy is still there for the full-corpus oracle)
+            name = "synthetic-1B-pq16-nc993127-nprobe64"
+            _, _, _, _, s_np, s_mc, s_ef, s_nq = WORKLOADS[name]
+            ent, lg, dg = measure(g, s_nq, d_q, s_np, s_mc, s_ef)
+            ent["workload"] = name
+            if ox is not None:
+                ox.set_params(s_np, s_mc, s_ef)
+                r_d, r_l, _, _, _ = ox.search_batch(queries[:2000], 1, nthr)
+                ent["parity"] = parity_of(r_l, r_d, lg, dg, 2000)
+            out["secondary"].append(ent)
+            ox = None
+            C._host = None   # 21 GB of host lists: the next corpora bring their own (sparse) views
+
+            # (2) configs[1], (3) the metric's shape on clustered centroids: own corpora, oracle on a SPARSE host view (only
+            # the lists its own walk probes for the sample are materialised, tests/test_gpu_configs_1b.py)
+            for name in ("synthetic-100M-pq16-nc131072-nprobe32", "clustered-1B-pq16-nc993127-nprobe32"):
+                CC = Corpus(pkg, synth, name, args.seed, dev, local_rank)
+                CC.g.set_stream(torch.cuda.current_stream().cuda_stream)
+                _, _, _, _, s_np, s_mc, s_ef, s_nq = WORKLOADS[name]
+                sq = CC.queries(s_nq, args.seed + 1)
+                ent, lg, dg = measure(CC.g, s_nq, torch.from_numpy(sq).to(dev), s_np, s_mc, s_ef)
+                ent["workload"] = name
+                ent["centroids"] = CC.kind
                 if not args.no_cpu_baseline:
                     from oracle import orc
-                    if oxx is None:
-                        oxx = CC.oracle(synth, orc)
-                    oxx.set_params(s_np, s_mc, s_ef)
                     n_chk = 2000
-                    try:
-                        nthr = min(16, len(os.sched_getaffinity(0)))
-                    except AttributeError:
-                        nthr = 8
+                    arrays = synth.synthetic_codes_sparse(CC.code_seed, CC.tb["offsets"], CC.M)
+                    graph = orc.Hnsw.from_arrays(CC.counts, CC.links, CC.vectors, 16, 0)
+                    oxx = orc.Index(CC.d, CC.M, graph, CC.tb["pq_centroids"], CC.tb["norm_table"], CC.tb["offsets"],
+                                    arrays[0], arrays[1], arrays[2], CC.centroid_norms)
+                    oxx.set_params(s_np, s_mc, s_ef)
+                    _, _, cid0, _, _ = oxx.search_batch(sq[:n_chk], 1, nthr)   # pass 1: which lists does its walk probe
+                    probed = cid0.ravel()
+                    synth.synthetic_codes_sparse(CC.code_seed, CC.tb["offsets"], CC.M, probed[probed < CC.nc], into=arrays)
                     r_d, r_l, _, _, _ = oxx.search_batch(sq[:n_chk], 1, nthr)
-                    lg, dg = s_ll.cpu().numpy()[:n_chk, 0], s_dd.cpu().numpy()[:n_chk, 0]
-                    ent["parity"] = {"queries_checked": n_chk, "labels_equal": int((r_l[:, 0] == lg).sum()),
-                                     "distances_bit_equal": int((r_d[:, 0].view(np.uint32) == dg.view(np.uint32)).sum())}
+                    ent["parity"] = parity_of(r_l, r_d, lg, dg, n_chk)
+                    graph.free()
+                    del arrays, oxx
                 out["secondary"].append(ent)
-                if own:
-                    gg.close()
+                CC.g.close()
+                del CC
+
+            # (4) Recall@1 itself (the metric is "queries/sec @ Recall@1"; the reference's drivers print it,
+            # tests/test_ivfhnsw_sift1b.cpp:173-215): a 10 M-vector index of clustered data built by the library's own
+            # pipeline on the device -- insertion-loop graph, Lloyd-trained code books, assignment + encoding, exact ground
+            # truth (tests/synth.py make_recall_corpus) -- searched by the device path and by the CPU port
+            name = "clustered-10M-pq16-nc16384-recall"
+            t0 = time.time()
+            rc = synth.make_recall_corpus(pkg, args.seed + 11, 16384, 10_000_000, nq=10000, device=local_rank,
+                                          query_noise=24.0, log=log)
+            gr_ = pkg.GpuIndex(local_rank)
+            gr_.set_stream(torch.cuda.current_stream().cuda_stream)
+            gr_.upload_ivf(rc["d"], rc["code_size"], rc["offsets"], rc["ids"], rc["codes"], rc["norm_codes"],
+                           rc["centroid_norms"], rc["pq_centroids"], rc["norm_table"])
+            gr_.upload_quantizer(rc["counts"], rc["links"], rc["centroids"], 0)
+            ent, lg, dg = measure(gr_, 10000, torch.from_numpy(rc["queries"]).to(dev), 32, 10000, 80)
+            ent["workload"] = name
+            ent["built_in_s"] = round(time.time() - t0, 1)
+            rec = {"device": round(float((lg == rc["gt"]).mean()), 4)}
+            if not args.no_cpu_baseline:
+                from oracle import orc
+                graph = orc.Hnsw.from_arrays(rc["counts"], rc["links"], rc["centroids"], 16, 0)
+                oxx = orc.Index(rc["d"], rc["code_size"], graph, rc["pq_centroids"], rc["norm_table"], rc["offsets"],
+                                rc["ids"], rc["codes"], rc["norm_codes"], rc["centroid_norms"])
+                oxx.set_params(32, 10000, 80)
+                t0 = time.perf_counter()
+                r_d, r_l, _, _, _ = oxx.search_batch(rc["queries"], 1, nthr)
+                t_cpu = time.perf_counter() - t0
+                ent["parity"] = parity_of(r_l, r_d, lg, dg, 10000)
+                rec["cpu_port"] = round(float((r_l[:, 0] == rc["gt"]).mean()), 4)
+                rec["equal"] = rec["cpu_port"] == rec["device"]
+                ent["cpu_port_queries_per_s"] = round(10000 / t_cpu, 1)
+                graph.free()
+            rec["ground_truth"] = "exact nearest base vector of every query (ivfhnsw_gpu_knn, f32 MFMA brute force)"
+            ent["recall_at_1"] = rec
+            out["secondary"].append(ent)
+            gr_.close()
         print(json.dumps(out), flush=True)
 
     g.close()

@@ -116,9 +116,9 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
 int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h);
 
 /* Large batches as two uneven parts on two streams inside ivfhnsw_gpu_search[_dev] (a batched extension; the reference
- * searches one query per call, IndexIVF_HNSW.cpp:232-293).  permille = share of the batch in the first part (780 is
- * what measured best: 1.81 -> 1.67 ms per 10 k queries at the 1B shape); 0 = off, the default (also set by the
- * environment variable IVFHNSW_SPLIT at ivfhnsw_gpu_create).  The second part runs on an internal view of the handle;
+ * searches one query per call, IndexIVF_HNSW.cpp:232-293).  permille = share of the batch in the first part; 780, the
+ * default since ABI 9, is what measured best (1.81 -> 1.67 ms per 10 k queries at the 1B shape); 0 = one part (also set
+ * by the environment variable IVFHNSW_SPLIT at ivfhnsw_gpu_create).  The second part runs on an internal view of the handle;
  * its walk fills the tail of the first part's, the first part's table + scan run beside it.  Results, ordering behind
  * the handle's stream and error reporting are those of the unsplit call.  Applies to calls of >= 8192 queries without
  * given coarse results, out_keys or heap-order k > 1. */

@@ -358,8 +358,9 @@ int ivfhnsw_gpu_device_count(int *count)
 static int split_permille_env()
 {
     static const int v = [] {
+        // on by default since round 3 (780 permille in the first part measured best); IVFHNSW_SPLIT=0 = one part
         const char *e = getenv("IVFHNSW_SPLIT");
-        const int x = (e && *e) ? atoi(e) : 0;
+        const int x = (e && *e) ? atoi(e) : 780;
         return (x > 0 && x < 1000) ? x : 0;
     }();
     return v;
@@ -1273,10 +1274,13 @@ static const size_t kMaxBatchAll = 1 << 17;
 // last round frees, and the first part's table + scan (LDS-bound) run beside it (HBM-bound).  Fork and join are events,
 // so the call keeps its contract: everything is ordered behind the caller's stream and complete when that stream gets
 // there.  Measured (tools/split_probe.py, 1B corpus, 10 k queries): 1.81 -> 1.67 ms per batch, the first part's scan at
-// 4.8 instead of 5.0 TB/s; three parts give no more, four lose.  Off by default (ivfhnsw_gpu_set_batch_split, or
-// IVFHNSW_SPLIT = permille of the batch in the first part): the second part's scan is a single round of workgroups and
-// drags the scan's average rate from 0.62 to 0.58 of the HBM peak while the step gains 8 %.  Not for sharded calls (their resolve step needs one plan), heap-order k > 1 (one
-// candidate stream), given coarse results (no walk to overlap) or batches below two rounds of the walk.
+// 4.8 instead of 5.0 TB/s; three parts give no more, four lose.  ON by default since round 3 (780 permille in the first
+// part; ivfhnsw_gpu_set_batch_split(h, 0) or IVFHNSW_SPLIT=0 = one part): a plain search_dev call should deliver the
+// fastest exact form.  The price is in the scan's accounting: two launches per step, the first slowed a little by the walk
+// beside it, the second a single round of workgroups -- 17 B x all codes over the summed launch time is 0.58-0.59 of the
+// HBM peak where the one-launch form reads 0.62 (bench.py reports both).  Not for sharded calls (their resolve step
+// needs one plan), heap-order k > 1 (one candidate stream), given coarse results (no walk to overlap) or batches below
+// two rounds of the walk.
 static const size_t kSplitMinNq = 8192;
 
 int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille)
