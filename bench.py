@@ -480,11 +480,18 @@ def main():
         torch.cuda.synchronize()
         el_sp = time.perf_counter() - t_sp
         st1 = g.stage_ms()
+        g.set_profiling(1)      # ... and every stage of the one-part shape, in a few extra steps
+        g.reset_stage_ms()
+        for _ in range(10):
+            g.search_dev(nq, 1, d_q, sp_d, sp_l, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
+        torch.cuda.synchronize()
+        st1_all = g.stage_ms()
         g.set_profiling(False)
         g.set_batch_split(780)
         r1 = scan_roofline(g, M, st1, None, n_sp)
         one_part = {"steps": n_sp, "queries_per_s": round(nq * n_sp / el_sp, 1), "ms_per_batch": round(el_sp / n_sp * 1e3, 4),
                     "scan_avg_launch_ms": r1["avg_launch_ms"], "scan_gbps": r1["achieved"], "scan_frac_of_hbm_peak": r1["frac"],
+                    "stage_ms_per_step": {k_: round(v_[0] / 10.0, 4) for k_, v_ in st1_all.items()},
                     "results_equal_to_default": bool(torch.equal(sp_l, d_lab)) and
                     bool(torch.equal(sp_d.view(torch.int32), d_dist.view(torch.int32)))}
         # leave the handle as the timed region left it: the last call a two-part one (scan counts, kernel name)
@@ -542,6 +549,8 @@ def main():
         traffic, walk_traffic = pmc_traffic(args.workload) if single else (None, None)
         walk_ms, walk_n = stage["coarse"]
         walk_avg_ms = walk_ms / max(1, walk_n)
+        if one_part is not None:   # two overlapping walk launches per step say nothing per launch: the one-part shape's walk
+            walk_avg_ms = one_part["stage_ms_per_step"]["coarse"]
         walk_gbps = None if walk_traffic is None or walk_avg_ms <= 0 else round(walk_traffic / (walk_avg_ms * 1e-3), 1)
         if world == 1:
             sharding = "replicas=1"
@@ -581,12 +590,15 @@ def main():
             # the kernel's exact rejection filter mostly does not read) is reported separately by the cpu_baseline leg
             "roofline_walk": {
                 "bound": "hbm, random kilobyte pieces (DESIGN.md 3.2: at 993 127 nodes the walk runs near the rate HBM serves them; on cache-resident graphs its instruction stream binds)", "kernel": "hnsw_walk_kernel",
+                "shape": "the whole batch in one launch (one_part): the default path's two walk launches overlap each other",
                 "avg_launch_ms": round(walk_avg_ms, 4), "traffic": walk_traffic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
             "stage_ms_per_step": {k: round(v[0] / max(1, args.steps), 4) for k, v in stage.items()},
-            "stage_note": "scan: HIP events over the timed region; the other stages (the walk too): %d extra steps with every "
-                          "stage bracketed (six event pairs per step cost 2.3 %% of it)" % n_aux,
+            "stage_note": "sums of launch durations per step; with the batch split the two parts' launches OVERLAP, so the sum "
+                          "exceeds the step (one_part.stage_ms_per_step has the one-launch-per-kernel shape).  scan: HIP "
+                          "events over the timed region; the other stages: %d extra steps with every stage bracketed (six "
+                          "event pairs per step cost 2.3 %% of it)" % n_aux,
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
             "batch_split": {"parts": 2 if split_active else 1, "first_part_permille": 780 if split_active else None,

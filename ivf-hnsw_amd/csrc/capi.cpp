@@ -134,7 +134,9 @@ struct ivfhnsw_gpu {
     void *visited_zero_ptr = nullptr; // ... of this allocation
     size_t visited_zero_bytes = 0;
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
-        w_slen, w_counter, w_tail;
+        w_slen, w_counter, w_tail, w_redo;
+    bool lat_defer_redo = false; // host-pointer small batches: the latency walk flags a tie overflow, the call repeats itself
+    bool latency_off = false;    // ... on the throughput walk
     // staging for the host-pointer entry point
     DevBuf s_q, s_cid, s_cd, s_dist, s_lab, s_keys, s_len;
     HostBuf p_in, p_out; // pinned: small batches
@@ -392,7 +394,8 @@ int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
     }
     h->own_stream = true;
     h->split_pm = split_permille_env();
-    if (h->w_status.ensure(2 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 2 * sizeof(uint32_t)) != hipSuccess) {
+    // [0] status bits, [1] the walk's query counter, [2] queries on the redo list, [3] the redo launch's counter
+    if (h->w_status.ensure(4 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
         ivfhnsw_gpu_destroy(h);
         return fail(IVFHNSW_ERR_HIP, "cannot allocate the device status word");
     }
@@ -424,7 +427,7 @@ int ivfhnsw_gpu_destroy(ivfhnsw_gpu *h)
     DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes, &h->ids,
                      &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links, &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->q_links_c, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub,
                      &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys, &h->w_cid, &h->w_cd,
-                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab, &h->s_keys, &h->s_len};
+                     &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->w_redo, &h->k_q, &h->k_x, &h->k_qn, &h->k_xn, &h->k_part, &h->k_ids, &h->k_dists, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd, &h->s_dist, &h->s_lab, &h->s_keys, &h->s_len};
     for (auto *b : all)
         b->release();
     h->p_in.release();
@@ -836,26 +839,51 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         const char *e = getenv("IVFHNSW_LATENCY_MAX_NQ");
         return (e && *e) ? (size_t)atol(e) : (size_t)256;
     }();
-    if (nq <= lat_max_nq && coarse_latency_supported(h->gr, (int)efSearch)) {
+    // scratch of the walk: first half the visited bitmaps (the LDS set's overflow store), second half the tail bitmaps
+    // of the redo form (walk_set.h TailSpill) -- always at the middle of the ALLOCATION, so that no launch's visited area
+    // ever overlaps them; both halves zero between launches
+    auto walk_scratch = [&](size_t nslots, uint32_t **tails) -> int {
+        int r = h->w_visited.ensure(words * sizeof(uint32_t) * std::max<size_t>(nslots, 64) * 2);
+        if (r)
+            return r;
+        if (h->w_visited.p != h->visited_zero_ptr || h->w_visited.bytes != h->visited_zero_bytes) {
+            HIP_TRY(hipMemsetAsync(h->w_visited.p, 0, h->w_visited.bytes, h->stream)); // (re)allocated: contents unknown
+            h->visited_zero = true;
+            h->visited_zero_ptr = h->w_visited.p;
+            h->visited_zero_bytes = h->w_visited.bytes;
+        }
+        *tails = reinterpret_cast<uint32_t *>(h->w_visited.as<char>() + h->w_visited.bytes / 2);
+        return h->w_redo.ensure(nq * sizeof(uint32_t));
+    };
+    uint32_t *tails = nullptr;
+    if (!h->latency_off && nq <= lat_max_nq && coarse_latency_supported(h->gr, (int)efSearch)) {
+        uint32_t *hdr = h->w_status.as<uint32_t>() + 2;
+        const bool defer = h->lat_defer_redo; // the caller synchronises and reads the status word itself
+        if (!defer) {
+            if ((rc = walk_scratch(64, &tails)))
+                return rc;
+            HIP_TRY(hipMemsetAsync(hdr, 0, 2 * sizeof(uint32_t), h->stream));
+        }
         HIP_TRY(launch_coarse_latency(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                                      d_coarse_dists, h->w_status.as<uint32_t>(), h->walk_zero_keys, h->walk_zero_done));
+                                      d_coarse_dists, h->w_status.as<uint32_t>(), h->walk_zero_keys, h->walk_zero_done,
+                                      defer ? nullptr : hdr, defer ? nullptr : h->w_redo.as<uint32_t>()));
         h->walk_zeroed = h->walk_zero_keys != nullptr;
         h->walk_zero_keys = nullptr; // consumed: set by search_dev right before the call, never carried over
         h->walk_zero_done = nullptr;
+        if (!defer)
+            HIP_TRY(launch_coarse_redo(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
+                                       d_coarse_dists, h->w_visited.as<uint32_t>(), words, h->w_status.as<uint32_t>(), hdr,
+                                       h->w_redo.as<uint32_t>(), tails, 64));
         return IVFHNSW_OK;
     }
     {
         const int nslots = (int)std::min<size_t>(nq, (size_t)coarse_slots_for((int)efSearch));
-        if ((rc = h->w_visited.ensure(words * sizeof(uint32_t) * nslots)))
+        if ((rc = walk_scratch((size_t)nslots, &tails)))
             return rc;
-        if (h->w_visited.p != h->visited_zero_ptr || h->w_visited.bytes != h->visited_zero_bytes) {
-            h->visited_zero = false; // (re)allocated: contents unknown
-            h->visited_zero_ptr = h->w_visited.p;
-            h->visited_zero_bytes = h->w_visited.bytes;
-        }
         HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
                               d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
-                              h->w_status.as<uint32_t>() + 1, h->w_visited.bytes, &h->visited_zero));
+                              h->w_status.as<uint32_t>() + 1, h->w_visited.bytes / 2, &h->visited_zero,
+                              h->w_redo.as<uint32_t>(), tails, 64));
     }
     return IVFHNSW_OK;
 }
@@ -1659,17 +1687,32 @@ int ivfhnsw_gpu_search(ivfhnsw_gpu *h, size_t nq, size_t k, const float *queries
             memcpy(pin + in_q + in_c, coarse_dists, in_c);
         }
         uint32_t *pst = reinterpret_cast<uint32_t *>(pout + out_d + out_l);
-        h->tail_status_out = pst;
-        rc = ivfhnsw_gpu_search_dev(h, nq, k, reinterpret_cast<const float *>(pin),
-                                    coarse_ids ? reinterpret_cast<const uint32_t *>(pin + in_q) : nullptr,
-                                    coarse_ids ? reinterpret_cast<const float *>(pin + in_q + in_c) : nullptr, p,
-                                    reinterpret_cast<float *>(pout), reinterpret_cast<int64_t *>(pout + out_d), nullptr);
-        h->tail_status_out = nullptr;
-        if (rc)
-            return rc;
-        if (!h->tail_wrote_status)
-            HIP_TRY(hipMemcpyAsync(pst, h->w_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        // The latency walk keeps at most 64 exact ties at the efSearch boundary.  This call synchronises anyway, so instead
+        // of a redo launch behind every one-query call the walk only raises a status bit, and the call repeats itself once
+        // on the throughput walk, whose redo form has no such limit (hnswalg.cpp:67-68,93 has none either).
+        for (int attempt = 0; attempt < 2; attempt++) {
+            h->tail_status_out = pst;
+            h->lat_defer_redo = attempt == 0;
+            h->latency_off = attempt == 1;
+            rc = ivfhnsw_gpu_search_dev(h, nq, k, reinterpret_cast<const float *>(pin),
+                                        coarse_ids ? reinterpret_cast<const uint32_t *>(pin + in_q) : nullptr,
+                                        coarse_ids ? reinterpret_cast<const float *>(pin + in_q + in_c) : nullptr, p,
+                                        reinterpret_cast<float *>(pout), reinterpret_cast<int64_t *>(pout + out_d), nullptr);
+            h->tail_status_out = nullptr;
+            h->lat_defer_redo = false;
+            h->latency_off = false;
+            if (rc)
+                return rc;
+            if (!h->tail_wrote_status)
+                HIP_TRY(hipMemcpyAsync(pst, h->w_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (attempt == 0 && (*pst & kStatusHnswTieOverflow)) {
+                *pst &= ~kStatusHnswTieOverflow;
+                HIP_TRY(hipMemcpy(h->w_status.p, pst, sizeof(uint32_t), hipMemcpyHostToDevice)); // bit consumed
+                continue;
+            }
+            break;
+        }
         memcpy(distances, pout, nq * k * sizeof(float));
         memcpy(labels, pout + out_d, out_l);
         return *pst ? check_status(h) : IVFHNSW_OK;
@@ -1863,7 +1906,7 @@ int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
     const DevBuf *all[] = {&h->goff, &h->loff, &h->cnorm, &h->pqc, &h->ntab, &h->opq_at, &h->codes, &h->ncodes,
                            &h->ids, &h->g_alpha, &h->g_nn, &h->g_sizes, &h->g_inter, &h->q_counts, &h->q_links,
                            &h->q_vectors, &h->q_qrows, &h->q_nbrows, &h->q_nbnorms, &h->q_fat, &h->q_links_c, &h->e_pqc, &h->e_ntab, &h->e_a, &h->e_at, &h->e_x, &h->e_idx, &h->e_dist, &h->e_res, &h->e_tmp, &h->e_codes, &h->e_ncodes, &h->cg_q, &h->cg_cidx, &h->cg_ids, &h->cg_dists, &h->gc_nn, &h->cg_cvn, &h->cg_tab, &h->cg_tab2, &h->cg_off, &h->cg_alpha2, &h->cg_sub, &h->w_xq, &h->w_luts, &h->w_segs, &h->w_lpos, &h->w_hdr, &h->w_keys,
-                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
+                           &h->w_cid, &h->w_cd, &h->w_qsd, &h->w_totals, &h->w_visited, &h->w_status, &h->w_stream, &h->w_slen, &h->w_counter, &h->w_tail, &h->w_redo, &h->k_q, &h->k_x, &h->k_qn, &h->k_xn, &h->k_part, &h->k_ids, &h->k_dists, &h->t_x, &h->t_y, &h->t_cb, &h->t_assign, &h->t_part, &h->t_c, &h->s_q, &h->s_cid, &h->s_cd,
                            &h->s_dist, &h->s_lab};
     uint64_t s = 0;
     for (auto *b : all)

@@ -168,7 +168,16 @@ hipError_t launch_resolve(hipStream_t s, const IvfTables &t, const Seg *segs, co
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
                          size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query,
-                         size_t visited_bytes = 0, bool *visited_zero = nullptr); // in/out: the whole scratch is zero
+                         size_t visited_bytes = 0, bool *visited_zero = nullptr, // in/out: the whole scratch is zero
+                         // queries the fast form cannot finish (> 64 exact ties at the efSearch boundary) are listed in
+                         // redo_list [nq] and walked again by launch_coarse_redo, which launch_coarse ends with;
+                         // next_query must be followed by two more words (the list's header); tail_bitmaps
+                         // [tail_slots][words] zero on entry and on exit (walk_set.h TailSpill)
+                         uint32_t *redo_list = nullptr, uint32_t *tail_bitmaps = nullptr, int tail_slots = 0);
+hipError_t launch_coarse_redo(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
+                              uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
+                              size_t visited_words_per_slot, uint32_t *status, uint32_t *redo_hdr, uint32_t *redo_list,
+                              uint32_t *tail_bitmaps, int tail_slots);
 int coarse_slots_for(int ef);
 // one workgroup per query on the fat graph (small batches: the reference's one-query-per-call drivers)
 bool coarse_latency_supported(const GraphTables &g, int ef);
@@ -176,9 +185,10 @@ size_t coarse_latency_fat_bytes(const GraphTables &g);
 hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat);
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                                  uint32_t *coarse_ids, float *coarse_dists, uint32_t *status,
-                                 uint64_t *zero_keys = nullptr, uint32_t *zero_done = nullptr); // [nq] words to clear
+                                 uint64_t *zero_keys = nullptr, uint32_t *zero_done = nullptr, // [nq] words to clear
+                                 uint32_t *redo_hdr = nullptr, uint32_t *redo_list = nullptr); // zeroed header: see launch_coarse
 // bits of the device status word
-constexpr uint32_t kStatusHnswTieOverflow = 1u;
+constexpr uint32_t kStatusHnswTieOverflow = 1u; // latency walk on the synchronous host-pointer path only: the call repeats itself (capi.cpp)
 constexpr uint32_t kStatusTopkStreamOverflow = 2u;
 // synthetic corpus: uniform bytes from a counter hash; ids = running index
 // construction side (kernels_encode.hip): IndexIVF_HNSW.cpp:75-121

@@ -199,12 +199,21 @@ __device__ __forceinline__ unsigned long long walk_stamp()
 
 // FMODE: the exact rejection filter -- 0 off, 1 gather from GraphTables::qrows, 2 neighbour rows (nbrows),
 // 3 neighbour rows with the survivors entered into the visited set late (see filter_first)
-template <int NCH, int MINW, int TAGW, int FMODE, bool STAMPS = false>
+// SPILL: the "redo" instantiation.  The fast forms keep evicted candidates that tie with the lower bound in a kTailCap-entry
+// LDS tail; a query that needs more (65 exact distance ties at the efSearch boundary -- the reference has no limit,
+// hnswalg.cpp:67-68,93) is appended to the redo list instead of being finished, and walked again by this form, whose tail
+// overflows into a per-wavefront global bitmap (walk_set.h TailSpill).  Keeping that code out of the fast forms matters:
+// compiled into them it cost 17 % of the walk (1.365 -> 1.60 ms per 10 k queries, same box) in registers and scratch.
+// redo_hdr: [0] number of listed queries, [1] the redo launch's own query counter (both zeroed with next_query); redo_list:
+// the queries.
+template <int NCH, int MINW, int TAGW, int FMODE, bool STAMPS = false, bool SPILL = false>
 __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, const float *__restrict__ xq, int nq, int nprobe,
                                                        int ef, uint32_t *__restrict__ coarse_ids,
                                                        float *__restrict__ coarse_dists,
                                                        uint32_t *__restrict__ visited, size_t vwords,
                                                        uint32_t *__restrict__ status, uint32_t *__restrict__ next_query,
+                                                       uint32_t *__restrict__ redo_hdr, uint32_t *__restrict__ redo_list,
+                                                       uint32_t *__restrict__ tail_bitmaps = nullptr, // SPILL: [grid][vwords]
                                                        unsigned long long *__restrict__ stamp_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -243,6 +252,10 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     auto enc_id = [](uint32_t id, uint32_t c) { return CK ? (id << 7) | c : id; };
     auto dec_id = [](uint32_t e) { return CK ? e >> 7 : e; };
     uint32_t *bm = visited + (size_t)blockIdx.x * vwords;
+    TailSpill spill;
+    spill.bm = SPILL ? tail_bitmaps + (size_t)blockIdx.x * vwords : nullptr;
+    spill.hi = -1;
+    spill.count = 0;
     // The bitmap must be clean before a query uses it.  With the LDS set it is only the overflow store (rarely touched):
     // the launcher hands it over zeroed ONCE (g.visited_clean) and a block that did touch it wipes it before it leaves,
     // so launches do not start by clearing n / 8 bytes per resident wavefront (508 MB per launch at 993 127 nodes --
@@ -251,8 +264,16 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
 
     for (;;) {
         int q = 0;
-        if (lane == 0)
-            q = (int)atomicAdd(next_query, 1u);
+        if constexpr (SPILL) {
+            // the queries the fast forms could not finish
+            if (lane == 0) {
+                const uint32_t i = atomicAdd(&redo_hdr[1], 1u);
+                q = i < redo_hdr[0] ? (int)redo_list[i] : nq;
+            }
+        } else {
+            if (lane == 0)
+                q = (int)atomicAdd(next_query, 1u);
+        }
         q = __builtin_amdgcn_readfirstlane(q);
         if (q >= nq)
             break;
@@ -383,7 +404,8 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         for (int cc = 0; cc < NCH; cc++)
             R.r[cc] = ~0ull;
         int n = 1;     // entries in R (== topResults.size())
-        int ntail = 0; // evicted entries whose distance still equals the lower bound
+        int ntail = 0; // evicted entries whose distance still equals the lower bound (SPILL: in LDS, or ALL in the bitmap)
+        uint32_t tail_db = 0; // SPILL: that distance's bits
         {
             // hnswalg.cpp:56-62: seed with the enter point
             const float d0 = l2_ref_order_quad(g.vectors + (size_t)g.enterpoint * g.d, s_q, g.d, lane & 3);
@@ -423,14 +445,27 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 }
                 if (ntail > 0 && db == key_dist_bits(R.get(n - 1))) {
                     // tail entries share this distance; the larger id pops first
-                    for (int t = 0; t < ntail; t++)
-                        if (key_id(tail[t]) > pick_id) {
-                            pick_id = key_id(tail[t]);
-                            pick_tail = t;
+                    if (SPILL && spill.count > 0) {
+                        const uint32_t sid = spill.peek_max(lane);
+                        const uint32_t senc = enc_id(sid, CK ? (uint32_t)g.counts[sid] : 0u);
+                        if (senc > pick_id) {
+                            pick_id = senc;
+                            pick_tail = kTailCap; // "in the bitmap"
                         }
+                    } else {
+                        for (int t = 0; t < ntail; t++)
+                            if (key_id(tail[t]) > pick_id) {
+                                pick_id = key_id(tail[t]);
+                                pick_tail = t;
+                            }
+                    }
                     if (pick_tail >= 0)
                         pick = -1;
                 }
+            } else if (SPILL && spill.count > 0) {
+                const uint32_t sid = spill.peek_max(lane);
+                pick_id = enc_id(sid, CK ? (uint32_t)g.counts[sid] : 0u);
+                pick_tail = kTailCap;
             } else if (ntail > 0) {
                 pick_tail = 0;
                 pick_id = key_id(tail[0]);
@@ -444,6 +479,9 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
             if (pick >= 0) {
                 R.mark_expanded(pick, lane);
+            } else if (SPILL && pick_tail == kTailCap) {
+                spill.remove(dec_id(pick_id), lane);
+                ntail--;
             } else {
                 __syncthreads();
                 if (lane == 0)
@@ -783,19 +821,35 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                     topk = R.get(n - 1);
                     // bookkeeping of candidates that left topResults but may still be popped
                     const uint32_t newmax = key_dist_bits(topk);
-                    if (ntail > 0 && key_dist_bits(tail[0]) != newmax)
+                    if (ntail > 0 && (SPILL ? tail_db : key_dist_bits(tail[0])) != newmax) {
                         ntail = 0; // lower bound moved below them: dead for good
+                        if (SPILL && spill.count > 0)
+                            spill.clear(lane);
+                    }
                     if (full && !(oldtop & 1ull) && key_dist_bits(oldtop) == newmax) {
-                        if (ntail < kTailCap) {
+                        if (SPILL)
+                            tail_db = newmax;
+                        if ((!SPILL || spill.count == 0) && ntail < kTailCap) {
                             __syncthreads();
                             if (lane == 0)
                                 tail[ntail] = oldtop;
                             ntail++;
                             __syncthreads();
+                        } else if constexpr (SPILL) {
+                            // the whole tail moves into the wavefront's global bitmap and stays there until it dies or drains
+                            if (spill.count == 0) {
+                                __syncthreads();
+                                for (int t = 0; t < ntail; t++)
+                                    spill.add(dec_id(key_id(tail[t])), lane);
+                                __syncthreads();
+                            }
+                            spill.add(dec_id(key_id(oldtop)), lane);
+                            ntail++;
                         } else {
-                            // more than kTailCap exact distance ties at the boundary: cannot be represented
+                            // more than kTailCap exact distance ties at the boundary: this form cannot finish the query --
+                            // it goes on the redo list (the SPILL form walks it again, results written there)
                             if (lane == 0)
-                                atomicOr(status, kStatusHnswTieOverflow);
+                                redo_list[atomicAdd(&redo_hdr[0], 1u)] = (uint32_t)q;
                             ntail = -1;
                             break;
                         }
@@ -811,18 +865,27 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
                 break;
         }
 
+        if (SPILL && spill.count > 0)
+            spill.clear(lane); // the tail bitmap is handed back all zero
         if (LDSVIS && __ballot(used_bitmap))
             bitmap_dirty = true;
         // searchKnn pops down to nprobe (hnswalg.cpp:229-233); IndexIVF_HNSW.cpp:249-259 unloads nearest first
+        if (ntail >= 0) { // (ntail < 0: on the redo list, the SPILL form writes this query's rows)
 #pragma unroll
-        for (int cc = 0; cc < NCH; cc++) {
-            const int i = cc * 64 + lane;
-            if (i < nprobe) {
-                const bool have = ntail >= 0 && i < n;
-                coarse_ids[(size_t)q * nprobe + i] = have ? dec_id(key_id(R.r[cc])) : 0xffffffffu;
-                coarse_dists[(size_t)q * nprobe + i] = have ? __uint_as_float(key_dist_bits(R.r[cc])) : 0.f;
+            for (int cc = 0; cc < NCH; cc++) {
+                const int i = cc * 64 + lane;
+                if (i < nprobe) {
+                    const bool have = i < n;
+                    coarse_ids[(size_t)q * nprobe + i] = have ? dec_id(key_id(R.r[cc])) : 0xffffffffu;
+                    coarse_dists[(size_t)q * nprobe + i] = have ? __uint_as_float(key_dist_bits(R.r[cc])) : 0.f;
+                }
             }
         }
+    }
+    if (SPILL) { // the redo form runs on bitmap-only visited sets inside scratch the fast forms expect to find zero
+        uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+        for (size_t w = lane; w < vwords / 4; w += 64)
+            bm4[w] = make_uint4(0u, 0u, 0u, 0u);
     }
     if (LDSVIS && bitmap_dirty) { // leave the overflow store as it was found
         uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
@@ -895,14 +958,18 @@ int coarse_slots_for(int ef)
 hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq, int nq, int nprobe, int ef,
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
                          size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query,
-                         size_t visited_bytes, bool *visited_zero)
+                         size_t visited_bytes, bool *visited_zero, uint32_t *redo_list, uint32_t *tail_bitmaps,
+                         int tail_slots)
 {
     if (nq == 0)
         return hipSuccess;
     GraphTables g = g_in;
-    if (ef > 1024 || ef < 1 || nprobe > ef || g.maxM > 64 || g.n >= 0x80000000u || (visited_words_per_slot & 3))
+    if (ef > 1024 || ef < 1 || nprobe > ef || g.maxM > 64 || g.n >= 0x80000000u || (visited_words_per_slot & 3) ||
+        !redo_list || !tail_bitmaps || tail_slots < 1)
         return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(next_query, 0, sizeof(uint32_t), s);
+    // next_query, and behind it the redo list's header (number of listed queries, the redo launch's counter)
+    uint32_t *redo_hdr = next_query + 1;
+    hipError_t e = hipMemsetAsync(next_query, 0, 3 * sizeof(uint32_t), s);
     if (e != hipSuccess)
         return e;
     // Waves per SIMD the kernel is built for (register budget and visited-set size follow from it).  Measured
@@ -953,7 +1020,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
     }
 #define IVFHNSW_WALK_F(N, W, T, F)                                                                                    \
     hipLaunchKernelGGL((hnsw_walk_kernel<N, W, T, F>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,         \
-                       coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query)
+                       coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, redo_hdr, redo_list)
 #define IVFHNSW_WALK_T(N, W, T)          \
     do {                                 \
         if (fmode == 3)                  \
@@ -1003,7 +1070,8 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
             });
         }
         hipLaunchKernelGGL((hnsw_walk_kernel<2, 4, 8, 2, true>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,
-                           coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, d_st);
+                           coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, redo_hdr,
+                           redo_list, nullptr, d_st);
         return hipGetLastError();
     }
     if (nch <= 1) {
@@ -1023,6 +1091,45 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
 #undef IVFHNSW_WALK
 #undef IVFHNSW_WALK_T
 #undef IVFHNSW_WALK_F
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    return launch_coarse_redo(s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot,
+                              status, redo_hdr, redo_list, tail_bitmaps, tail_slots);
+}
+
+// The queries a fast form of the walk (this file's, or the latency form of kernels_hnsw_lat.hip) could not finish: more
+// than kTailCap exact ties at the efSearch boundary.  The plainest exact form -- no rejection filter, global visited
+// bitmaps -- with the tail's overflow in global bitmaps (SPILL).  Always launched (the host cannot know the list's
+// length without a round trip): a few wavefronts that find the list empty and leave, ~4 us of stream time.
+hipError_t launch_coarse_redo(hipStream_t s, const GraphTables &g_in, const float *xq, int nq, int nprobe, int ef,
+                              uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
+                              size_t visited_words_per_slot, uint32_t *status, uint32_t *redo_hdr, uint32_t *redo_list,
+                              uint32_t *tail_bitmaps, int tail_slots)
+{
+    GraphTables g = g_in;
+    g.visited_clean = 0;
+    const int nch = (ef + 63) / 64;
+    const int slots = std::min(std::min(nq, tail_slots), 64);
+    const size_t shm = (size_t)g.d * sizeof(float) + 512 +
+                       (size_t)(kTailCap + ((ef <= 256 && ef + 8 > kTailCap) ? ef + 8 - kTailCap : 0)) * sizeof(unsigned long long);
+#define IVFHNSW_REDO(N)                                                                                               \
+    hipLaunchKernelGGL((hnsw_walk_kernel<N, 4, 0, 0, false, true>), dim3(slots), dim3(64), shm, s, g, xq, nq, nprobe, ef, \
+                       coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, redo_hdr + 1, redo_hdr, \
+                       redo_list, tail_bitmaps)
+    if (nch <= 1)
+        IVFHNSW_REDO(1);
+    else if (nch <= 2)
+        IVFHNSW_REDO(2);
+    else if (nch == 3)
+        IVFHNSW_REDO(3);
+    else if (nch <= 4)
+        IVFHNSW_REDO(4);
+    else if (nch <= 8)
+        IVFHNSW_REDO(8);
+    else
+        IVFHNSW_REDO(16);
+#undef IVFHNSW_REDO
     return hipGetLastError();
 }
 

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
                                                                     float *__restrict__ coarse_dists,
                                                                     uint32_t *__restrict__ status, int diag,
                                                                     unsigned long long *__restrict__ zero_keys,
-                                                                    uint32_t *__restrict__ zero_done)
+                                                                    uint32_t *__restrict__ zero_done,
+                                                                    uint32_t *__restrict__ redo_hdr,
+                                                                    uint32_t *__restrict__ redo_list)
 {
     // diag (STAMPS builds only, IVFHNSW_LAT_DIAG=1): the loaders skip their fetch -- results are garbage, what is read
     // off the stamps is the cost of the two barriers alone
@@ -465,8 +467,16 @@ __global__ __launch_bounds__(LAT_THREADS) void hnsw_walk_lat_kernel(GraphTables 
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 } else {
-                    if (lane == 0)
-                        atomicOr(status, kStatusHnswTieOverflow);
+                    // more than kTailCap exact ties at the efSearch boundary: this form cannot finish the query.  Async
+                    // callers get it walked again by the redo form (launch_coarse_redo, kernels_hnsw.hip: the list);
+                    // the synchronous host-pointer call asks for the status bit instead and repeats itself on the
+                    // throughput walk (capi.cpp: no redo launch on the one-query-per-call path)
+                    if (lane == 0) {
+                        if (redo_hdr)
+                            redo_list[atomicAdd(&redo_hdr[0], 1u)] = (uint32_t)q;
+                        else
+                            atomicOr(status, kStatusHnswTieOverflow);
+                    }
                     overflow = true;
                     break;
                 }
@@ -570,7 +580,7 @@ hipError_t launch_build_fat(hipStream_t s, const GraphTables &g, float *fat)
 
 hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                                  uint32_t *coarse_ids, float *coarse_dists, uint32_t *status, uint64_t *zero_keys_u64,
-                                 uint32_t *zero_done)
+                                 uint32_t *zero_done, uint32_t *redo_hdr, uint32_t *redo_list)
 {
     unsigned long long *zero_keys = reinterpret_cast<unsigned long long *>(zero_keys_u64);
     if (nq == 0)
@@ -594,7 +604,7 @@ hipError_t launch_coarse_latency(hipStream_t s, const GraphTables &g, const floa
         if (hipError_t e = raise_dyn_lds((const void *)kern, shm, attr[stamps ? 1 : 0]); e != hipSuccess)             \
             return e;                                                                                                 \
         hipLaunchKernelGGL(kern, dim3(nq), dim3(LAT_THREADS), shm, s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, \
-                           status, diag, zero_keys, zero_done);                                                                                   \
+                           status, diag, zero_keys, zero_done, redo_hdr, redo_list);                                                                                   \
     } while (0)
 #define IVFHNSW_LAT_J(N)       \
     do {                       \

@@ -42,6 +42,57 @@ __device__ __forceinline__ unsigned long long lanes_below(int n, int cc)
     return r >= 64 ? ~0ull : (r > 0 ? (1ull << r) - 1ull : 0ull);
 }
 
+// ---- the tail beyond kTailCap entries --------------------------------------------------------------------------------
+// Evicted candidates wait in the tail only while their distance EQUALS the set's maximum, so every tail entry has the
+// same distance and the tail is a SET OF IDS.  The reference has no limit on it (hnswalg.cpp:67-68,93: the candidate
+// heap is a std::priority_queue); up to kTailCap entries live in LDS, and when one more arrives the whole tail moves into
+// a per-wavefront global bitmap (n bits, zero between uses) and stays there until it dies or drains.  Rare path (65 exact
+// distance ties at the efSearch boundary): every access is a returning atomic, so no stale L1 line is ever read.
+struct TailSpill {
+    uint32_t *bm; // [words] of this wavefront, all zero outside spill mode
+    int hi;       // highest word that may hold a bit (-1: none); wave-uniform
+    int count;    // ids in the bitmap; > 0 = spill mode; wave-uniform
+
+    __device__ __forceinline__ void add(uint32_t id, int lane)
+    {
+        if (lane == 0)
+            atomicOr(&bm[id >> 5], 1u << (id & 31));
+        const int w = (int)(id >> 5);
+        hi = w > hi ? w : hi;
+        count++;
+    }
+    // largest id in the bitmap (count > 0); lowers `hi` to its word; the bit stays
+    __device__ __noinline__ uint32_t peek_max(int lane)
+    {
+        for (int w0 = hi; w0 >= 0; w0 -= 64) {
+            const int w = w0 - lane;
+            const uint32_t v = w >= 0 ? atomicOr(&bm[w], 0u) : 0u;
+            const unsigned long long m = __ballot(v != 0u);
+            if (m) {
+                const int first = __ffsll((long long)m) - 1; // lowest lane = highest word
+                const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
+                hi = w0 - first;
+                return (uint32_t)hi * 32u + (31u - (uint32_t)__clz((int)wv));
+            }
+        }
+        hi = -1;
+        return 0xffffffffu;
+    }
+    __device__ __forceinline__ void remove(uint32_t id, int lane)
+    {
+        if (lane == 0)
+            atomicAnd(&bm[id >> 5], ~(1u << (id & 31)));
+        count--;
+    }
+    __device__ __noinline__ void clear(int lane)
+    {
+        for (int w = lane; w <= hi; w += 64)
+            atomicAnd(&bm[w], 0u);
+        hi = -1;
+        count = 0;
+    }
+};
+
 template <int NCH> struct RSet {
     unsigned long long r[NCH]; // entry i: lane i & 63, register i >> 6
 

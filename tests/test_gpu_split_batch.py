@@ -1,7 +1,10 @@
 """With ivfhnsw_gpu_set_batch_split, batches of >= 8192 queries run as two uneven parts on two streams inside
 ivfhnsw_gpu_search_dev (capi.cpp search_dev_split: the second part on an internal view, fork / join by events).  The call's contract must not move: labels,
 distance bits and the scanned-code count of the oracle for the WHOLE batch, results complete behind the caller's
-stream, the status word of the second part reported, host-pointer entry point included."""
+stream, host-pointer entry point included.  (Round 2's docstring also claimed "the status word of the second part
+reported": the only status the walk could raise was the 64-entry tail overflow, which the test written for it never
+triggered; since round 3 that tail spills into global bitmaps and tests/test_gpu_walk_ties.py drives a graph that really
+overflows it through the one-part, two-part and host-pointer calls.)"""
 import numpy as np
 import pytest
 
