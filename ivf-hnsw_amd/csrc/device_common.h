@@ -305,16 +305,21 @@ __device__ __forceinline__ float quad_sum8(float alo, float ahi)
     return r;
 }
 
-// inclusive prefix sum over the 64 lanes of a wavefront
+// inclusive prefix sum over the 64 lanes of a wavefront: four row_shr steps inside every row of 16 lanes, then
+// row_bcast:15 / row_bcast:31 carry the rows' totals across (six DPP adds; the __shfl_up form was six ds_bpermute round
+// trips through the LDS crossbar -- ~100 cycles each for a lone wavefront, and the Grouping plan's serial pass takes two
+// scans per row)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, 64);
-        if (lane >= off)
-            v += o;
-    }
-    return v;
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)x;
 }
 
 // order-preserving map f32 -> u32 (and back) for packed (distance, scan position) keys

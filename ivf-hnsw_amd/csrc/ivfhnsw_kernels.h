@@ -85,6 +85,8 @@ struct GroupTables {
     const uint32_t *nn_idx;
     const uint32_t *sub_sizes;
     const float *inter_dists;
+    int dedupe; // the plan evaluates every distinct neighbour centroid of a query once (kernels_grouping.hip DEDUPE): set at
+                // upload when the neighbour lists of nearby groups overlap enough to pay for the hash set
 };
 
 struct GraphTables {
