@@ -737,12 +737,13 @@ def main():
 
             # (2) configs[1], (3) the metric's shape on clustered centroids: own corpora, oracle on a SPARSE host view (only
             # the lists its own walk probes for the sample are materialised, tests/test_gpu_configs_1b.py)
-            for name in ("synthetic-100M-pq16-nc131072-nprobe32", "clustered-1B-pq16-nc993127-nprobe32"):
+            for name in ("synthetic-100M-pq16-nc131072-nprobe32", "clustered-1B-pq16-nc993127-nprobe32",
+                         "clustered-grouping-1B-pq16-nc993127-nsubc64-opq-pruning"):
                 CC = Corpus(pkg, synth, name, args.seed, dev, local_rank)
                 CC.g.set_stream(torch.cuda.current_stream().cuda_stream)
                 _, _, _, _, s_np, s_mc, s_ef, s_nq = WORKLOADS[name]
                 sq = CC.queries(s_nq, args.seed + 1)
-                ent, lg, dg = measure(CC.g, s_nq, torch.from_numpy(sq).to(dev), s_np, s_mc, s_ef)
+                ent, lg, dg = measure(CC.g, s_nq, torch.from_numpy(sq).to(dev), s_np, s_mc, s_ef, pruning=CC.grouping)
                 ent["workload"] = name
                 ent["centroids"] = CC.kind
                 if not args.no_cpu_baseline:
@@ -750,9 +751,14 @@ def main():
                     n_chk = 2000
                     arrays = synth.synthetic_codes_sparse(CC.code_seed, CC.tb["offsets"], CC.M)
                     graph = orc.Hnsw.from_arrays(CC.counts, CC.links, CC.vectors, 16, 0)
+                    kw = {}
+                    if CC.grouping:
+                        kw = dict(nsubc=64, alphas=CC.gt["alphas"], nn_centroid_idxs=CC.gt["nn_centroid_idxs"],
+                                  subgroup_sizes=CC.gt["subgroup_sizes"], inter_centroid_dists=CC.gt["inter_centroid_dists"],
+                                  opq_A=CC.opq_A)
                     oxx = orc.Index(CC.d, CC.M, graph, CC.tb["pq_centroids"], CC.tb["norm_table"], CC.tb["offsets"],
-                                    arrays[0], arrays[1], arrays[2], CC.centroid_norms)
-                    oxx.set_params(s_np, s_mc, s_ef)
+                                    arrays[0], arrays[1], arrays[2], CC.centroid_norms, **kw)
+                    oxx.set_params(s_np, s_mc, s_ef, do_pruning=CC.grouping)
                     _, _, cid0, _, _ = oxx.search_batch(sq[:n_chk], 1, nthr)   # pass 1: which lists does its walk probe
                     probed = cid0.ravel()
                     synth.synthetic_codes_sparse(CC.code_seed, CC.tb["offsets"], CC.M, probed[probed < CC.nc], into=arrays)
