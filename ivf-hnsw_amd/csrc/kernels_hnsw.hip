@@ -1050,7 +1050,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
         const char *e = getenv("IVFHNSW_WALK_STAMPS");
         return e && atoi(e) == 1;
     }();
-    if (stamps && nch == 2 && tagw == 8 && fmode == 2 && occ == 4) {
+    if (stamps && nch == 2 && ((tagw == 8 && fmode == 2) || (tagw == 10 && fmode == 3)) && occ == 4) {
         // diagnostic build: per-segment cycle sums, printed when the process exits (never used for timing claims)
         static unsigned long long *d_st = nullptr;
         if (!d_st) {
@@ -1069,9 +1069,14 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
                 }
             });
         }
-        hipLaunchKernelGGL((hnsw_walk_kernel<2, 4, 8, 2, true>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,
-                           coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, redo_hdr,
-                           redo_list, nullptr, d_st);
+        if (tagw == 8)
+            hipLaunchKernelGGL((hnsw_walk_kernel<2, 4, 8, 2, true>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,
+                               coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, redo_hdr,
+                               redo_list, nullptr, d_st);
+        else // the form graphs of about a million nodes take (10-bit tags, late visited entry): round 3
+            hipLaunchKernelGGL((hnsw_walk_kernel<2, 4, 10, 3, true>), dim3(nslots), dim3(64), shm, s, g, xq, nq, nprobe, ef,
+                               coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot, status, next_query, redo_hdr,
+                               redo_list, nullptr, d_st);
         return hipGetLastError();
     }
     if (nch <= 1) {

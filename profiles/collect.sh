@@ -10,9 +10,13 @@ O=$PWD/gpurun_out/prof
 rm -rf "$O"; mkdir -p "$O"
 timeout -k 10 500 python3 bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.err"
 echo "[collect] bench done"; tail -c 300 "$O/bench.json"
-B="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-split --sustain-s 0 --in-flight 1 $BENCH_ARGS"
+# D = the default path (a batch as two parts on two streams: two launches of walk, plan + tables and scan per step);
+# B = the same steps in ONE part (--no-split): one launch shape per kernel, what the PMC passes are read on
+D="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --sustain-s 0 --in-flight 1 $BENCH_ARGS"
+B="$D --no-split"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o run -- $B > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o run -- $D > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats1" -o run -- $B > "$O/bench_one_part_under_rocprof.json" 2> "$O/stats1.err"
 echo "[collect] stats done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$O/pmc_fetch" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_fetch.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$O/pmc_write" -o run -- $B --steps 2 > /dev/null 2> "$O/pmc_write.err"
@@ -26,5 +30,6 @@ cd "$ROOT"
 python3 profiles/summarize.py "$O"/stats/*kernel_stats.csv "$O"/pmc_fetch/*counter_collection.csv "$O"/pmc_write/*counter_collection.csv \
   "$O"/pmc_sq/*counter_collection.csv "$O"/pmc_grbm/*counter_collection.csv > "$O/summary.md"
 cp "$O"/stats/*kernel_stats.csv "$O/kernel_stats.csv"
+cp "$O"/stats1/*kernel_stats.csv "$O/kernel_stats_one_part.csv"
 find "$O" -name "*counter_collection.csv" -delete
 ls -la "$O"
