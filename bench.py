@@ -264,6 +264,8 @@ def main():
                     help="N > 1: skip the extra `replica_groups` measurement (2 groups x N/2 shards on the same ranks)")
     ap.add_argument("--no-split", action="store_true", help="run every batch in ONE part (ivfhnsw_gpu_set_batch_split 0): "
                     "profiling runs that want one launch shape per kernel")
+    ap.add_argument("--no-one-part", action="store_true", help="skip the extra one_part measurement (profiling runs of the "
+                    "default path: every launch in the process then has the two-part shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[2] extra results")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("IVFHNSW_BENCH_SCALING", "weak"),
@@ -465,7 +467,7 @@ def main():
     # and the one the scan's rate reads best on.
     one_part = None
     split_active = world == 1 and nq >= 8192 and os.environ.get("IVFHNSW_SPLIT", "") != "0" and not args.no_split
-    if split_active:
+    if split_active and not args.no_one_part:
         g.set_batch_split(0)
         sp_d, sp_l = torch.empty_like(d_dist), torch.empty_like(d_lab)
         for _ in range(3):

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
     // so launches do not start by clearing n / 8 bytes per resident wavefront (508 MB per launch at 993 127 nodes --
     // it was ALL of the walk's WRITE_SIZE, 8 % of its traffic).
     bool bitmap_dirty = !(LDSVIS && g.visited_clean);
+    bool redo_ran = false; // SPILL: this wavefront walked a query (an empty redo list costs a launch and nothing else)
 
     for (;;) {
         int q = 0;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
         q = __builtin_amdgcn_readfirstlane(q);
         if (q >= nq)
             break;
+        redo_ran = true;
         if (STAMPS)
             st_t = walk_stamp();
 
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
     }
-    if (SPILL) { // the redo form runs on bitmap-only visited sets inside scratch the fast forms expect to find zero
+    if (SPILL && redo_ran) { // the redo form runs on bitmap-only visited sets inside scratch the fast forms expect to find zero
         uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
         for (size_t w = lane; w < vwords / 4; w += 64)
             bm4[w] = make_uint4(0u, 0u, 0u, 0u);

@@ -12,7 +12,7 @@ timeout -k 10 500 python3 bench.py $BENCH_ARGS > "$O/bench.json" 2> "$O/bench.er
 echo "[collect] bench done"; tail -c 300 "$O/bench.json"
 # D = the default path (a batch as two parts on two streams: two launches of walk, plan + tables and scan per step);
 # B = the same steps in ONE part (--no-split): one launch shape per kernel, what the PMC passes are read on
-D="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --sustain-s 0 --in-flight 1 $BENCH_ARGS"
+D="python3 $PWD/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --sustain-s 0 --in-flight 1 --no-one-part $BENCH_ARGS"
 B="$D --no-split"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o run -- $D > "$O/bench_under_rocprof.json" 2> "$O/stats.err"

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    n = name.replace("void ", "").replace("ivfhnsw_gpu_impl::", "")
+    n = name.replace("void ", "").replace("ivfhnsw_gpu_impl::", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0]
 
 
