@@ -69,12 +69,42 @@ void IndexIVF_HNSW::build_quantizer(const char *path_data, const char *path_info
     quantizer = new hnswlib::HierarchicalNSW(d, nc, M_, 2 * M_, efConstruction);
     std::cout << "Constructing quantizer\n";
     std::ifstream input(path_data, std::ios::binary);
-    std::vector<float> v(d);
-    for (size_t i = 0; i < nc; i++) {
-        readXvec<float>(input, v.data(), d);
-        if (i % 100000 == 0)
-            std::cout << i / (0.01 * nc) << " %\n";
-        quantizer->addPoint(v.data());
+    // IVFHNSW_BUILD=device: the insertion loop for all centroids at once on the device (ivfhnsw_gpu_build_graph: exact
+    // candidates on the matrix cores, then this very heuristic and connect step per node) -- seconds for a million
+    // centroids where the serial loop below takes hours (README.md:65 of the reference); the default keeps the serial
+    // loop, whose graph equals the reference's link for link.
+    static const bool on_device = [] {
+        const char *e = getenv("IVFHNSW_BUILD");
+        return e && std::string(e) == "device";
+    }();
+    if (on_device && nc > 1 && d % 4 == 0 && d <= 128 && 2 * M_ <= 64) {
+        std::vector<float> all(nc * d);
+        for (size_t i = 0; i < nc; i++)
+            readXvec<float>(input, all.data() + i * d, d);
+        std::vector<uint8_t> cnt(nc);
+        std::vector<idx_t> lk(nc * 2 * M_);
+        if (!gpu_ && ivfhnsw_gpu_create(0, &gpu_))
+            gpu_fail("ivfhnsw_gpu_create");
+        const size_t ncand = std::min<size_t>(80, std::max<size_t>(4 * M_, 2 * M_));
+        if (ivfhnsw_gpu_build_graph(gpu_, nc, d, all.data(), M_, 2 * M_, ncand, cnt.data(), lk.data()))
+            gpu_fail("ivfhnsw_gpu_build_graph");
+        for (size_t i = 0; i < nc; i++) {
+            uint8_t *rec = quantizer->get_linklist0((idx_t)i);
+            std::memset(rec, 0, quantizer->size_data_per_element);
+            rec[0] = cnt[i];
+            std::memcpy(rec + 1, lk.data() + i * 2 * M_, (size_t)cnt[i] * sizeof(idx_t));
+            std::memcpy(quantizer->getDataByInternalId((idx_t)i), all.data() + i * d, d * sizeof(float));
+        }
+        quantizer->cur_element_count = nc;
+        quantizer->enterpoint_node = 0;
+    } else {
+        std::vector<float> v(d);
+        for (size_t i = 0; i < nc; i++) {
+            readXvec<float>(input, v.data(), d);
+            if (i % 100000 == 0)
+                std::cout << i / (0.01 * nc) << " %\n";
+            quantizer->addPoint(v.data());
+        }
     }
     quantizer->SaveInfo(path_info);
     quantizer->SaveEdges(path_edges);

@@ -63,6 +63,13 @@ static int run(int argc, char **argv)
         g.SaveEdges(argv[8]);
         return 0;
     }
+    if (cmd == "build_quantizer" && argc == 9) {
+        // IndexIVF_HNSW::build_quantizer (IndexIVF_HNSW.cpp:34-66) as the drivers call it: centroids file -> info + edges files
+        const size_t n = atol(argv[3]), d = atol(argv[4]), M = atol(argv[5]), efc = atol(argv[6]);
+        ivfhnsw::IndexIVF_HNSW index(d, n, 16, 8);
+        index.build_quantizer(argv[2], argv[7], argv[8], M, efc);
+        return 0;
+    }
     if (cmd == "hnsw_search" && argc == 10) {
         hnswlib::HierarchicalNSW g(argv[2], argv[3], argv[4]);
         const size_t nq = atol(argv[6]), ef = atol(argv[7]), k = atol(argv[8]);

@@ -62,6 +62,27 @@ def test_hnsw_files_roundtrip_and_host_construction_equals_oracle(tmp_path):
     assert open(pe, "rb").read() == open(pe + "3", "rb").read()
 
 
+@pytest.mark.gpu
+def test_build_quantizer_on_the_device_equals_the_serial_loop_over_exact_candidates(tmp_path):
+    """IVFHNSW_BUILD=device: IndexIVF_HNSW::build_quantizer through ivfhnsw_gpu_build_graph -- the files it saves are the
+    ones the oracle's serial insertion loop over exact candidates leaves (M 16, maxM 32, 64 candidates); without the
+    variable it stays the reference-identical serial construction."""
+    rng = np.random.default_rng(14)
+    cents = synth.clustered_centroids(rng, 3000, 128)
+    pd = str(tmp_path / "c.fvecs")
+    hostio.write_xvecs(pd, cents)
+    env = dict(os.environ, IVFHNSW_BUILD="device")
+    subprocess.run([TOOL, "build_quantizer", pd, "3000", "128", "16", "100", str(tmp_path / "i_dev"), str(tmp_path / "e_dev")],
+                   check=True, env=env, capture_output=True)
+    ref = orc.Hnsw.build_exact(cents, 16, 32, 64)
+    ref.save(str(tmp_path / "i_ref"), str(tmp_path / "e_ref"))
+    assert open(tmp_path / "e_dev", "rb").read() == open(tmp_path / "e_ref", "rb").read()
+    tool("build_quantizer", pd, 3000, 128, 16, 100, str(tmp_path / "i_ser"), str(tmp_path / "e_ser"))
+    ser = orc.Hnsw.build(cents, M=16, efConstruction=100)
+    ser.save(str(tmp_path / "i_ser2"), str(tmp_path / "e_ser2"))
+    assert open(tmp_path / "e_ser", "rb").read() == open(tmp_path / "e_ser2", "rb").read()
+
+
 def test_host_walk_equals_oracle(tmp_path):
     rng = np.random.default_rng(5)
     base = synth.sift_like(rng, 150, 32)
