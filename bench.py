@@ -593,6 +593,8 @@ def main():
             "roofline_walk": {
                 "bound": "hbm, random kilobyte pieces (DESIGN.md 3.2: at 993 127 nodes the walk runs near the rate HBM serves them; on cache-resident graphs its instruction stream binds)", "kernel": "hnsw_walk_kernel",
                 "shape": "the whole batch in one launch (one_part): the default path's two walk launches overlap each other",
+                "traffic_calibration": "FETCH_SIZE x 2 + WRITE_SIZE; the x 2 measured on the walk's own access shapes "
+                                       "(profiles/r03_fetch_calibration.md: 2.000 for link rows, byte rows and float rows alike)",
                 "avg_launch_ms": round(walk_avg_ms, 4), "traffic": walk_traffic, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "traffic_gbps": walk_gbps, "frac": None if walk_gbps is None else round(walk_gbps / HBM_PEAK_GBPS, 4),
             },
