@@ -390,22 +390,34 @@ def main():
     # HIP events over the timed region around the kernel the roofline is about (the scan): an event pair costs ~7 us of
     # stream time, six pairs per step were 2.3 % of the step.  The other stages' times (the walk's too) come from a few
     # extra steps with every stage bracketed, after the region.
-    g.set_profiling(2)
-    g.reset_stage_ms()
+    prof_handles = sharded.handles() if sharded is not None else [g]
+    for h_ in prof_handles:
+        h_.set_profiling(2)
+        h_.reset_stage_ms()
     elapsed = timed_steps(torch, step, barrier, args.steps)
     if rank == 0:
         log("[bench] timed region: %d steps in %.3fs" % (args.steps, elapsed))
-    stage = g.stage_ms()
+    def stage_sum():
+        tot = {}
+        for h_ in prof_handles:
+            for k_, (ms_, n_) in h_.stage_ms().items():
+                a_, b_ = tot.get(k_, (0.0, 0))
+                tot[k_] = (a_ + ms_, b_ + n_)
+        return tot
+
+    stage = stage_sum()
     n_aux = 10
-    g.set_profiling(1)
-    g.reset_stage_ms()
+    for h_ in prof_handles:
+        h_.set_profiling(1)
+        h_.reset_stage_ms()
     timed_steps(torch, step, barrier, n_aux)
-    stage_all = g.stage_ms()
-    g.set_profiling(False)
+    stage_all = stage_sum()
+    for h_ in prof_handles:
+        h_.set_profiling(False)
     for name_, (ms_, n_) in stage_all.items():  # small stages: per step from the extra steps, scaled to the region
         if name_ != "scan":
             stage[name_] = (ms_ / n_aux * args.steps, int(round(n_ / n_aux * args.steps)))
-    ncodes, nsegs = g.last_scan_counts()  # per step, this shard
+    ncodes, nsegs = (sharded or g).last_scan_counts()  # per step, this shard (both parts of a two-part sharded step)
     lab_gpu = d_lab.cpu().numpy()[:, 0].copy()
     dist_gpu = d_dist.cpu().numpy()[:, 0].copy()
 

@@ -124,6 +124,13 @@ int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h);
  * given coarse results, out_keys or heap-order k > 1. */
 int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille);
 
+/* Options of this library (nothing of the reference's: its knobs are public members, below).  Unknown keys are refused.
+ *   "scan_pipe"  -1 (default) the library chooses, 0 never, 1 wherever the shape allows: table + scan of a list shard as
+ *                ONE software-pipelined kernel (kernels_scan3.hip) instead of two kernels.  A caller that runs a sharded
+ *                step as two overlapping parts (ShardedSearcher) turns it off: the pipelined form holds most of a CU's
+ *                LDS and cannot run beside the other part's walk. */
+int ivfhnsw_gpu_set_option(ivfhnsw_gpu *h, const char *key, long value);
+
 /* The search-time knobs the drivers set as public members (IndexIVF_HNSW.h:61-62, hnswalg.h:69,
  * IndexIVF_HNSW_Grouping.h:18). */
 typedef struct ivfhnsw_search_params {

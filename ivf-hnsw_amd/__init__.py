@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
     "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
-    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph",
+    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph", "ivfhnsw_gpu_set_option",
 )
 
 
@@ -113,6 +113,7 @@ def lib():
                                               C.c_size_t, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_knn_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_int, C.c_void_p, C.c_void_p]
+        L.ivfhnsw_gpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_set_batch_split.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
@@ -384,6 +385,10 @@ class GpuIndex:
         links = np.zeros((n, maxM), np.uint32)
         _check(lib().ivfhnsw_gpu_build_graph(self._h, n, d, _ptr(v), M, maxM, ncand, _ptr(counts), _ptr(links)))
         return counts, links
+
+    def set_option(self, key, value):
+        """Library options (ivfhnsw_gpu_set_option), e.g. ("scan_pipe", 0)."""
+        _check(lib().ivfhnsw_gpu_set_option(self._h, key.encode(), int(value)))
 
     def sync(self):
         _check(lib().ivfhnsw_gpu_sync(self._h))

@@ -135,6 +135,7 @@ struct ivfhnsw_gpu {
     size_t visited_zero_bytes = 0;
     DevBuf w_xq, w_luts, w_segs, w_lpos, w_hdr, w_keys, w_cid, w_cd, w_qsd, w_totals, w_visited, w_status, w_stream,
         w_slen, w_counter, w_tail, w_redo;
+    int opt_scan_pipe = -1;      // ivfhnsw_gpu_set_option "scan_pipe"
     bool lat_defer_redo = false; // host-pointer small batches: the latency walk flags a tie overflow, the call repeats itself
     bool latency_off = false;    // ... on the throughput walk
     // staging for the host-pointer entry point
@@ -1348,6 +1349,19 @@ int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille)
     return IVFHNSW_OK;
 }
 
+int ivfhnsw_gpu_set_option(ivfhnsw_gpu *h, const char *key, long value)
+{
+    if (!h || !key)
+        return fail(IVFHNSW_ERR_INVALID, "set_option: null argument");
+    if (!strcmp(key, "scan_pipe")) {
+        if (value < -1 || value > 1)
+            return fail(IVFHNSW_ERR_INVALID, "set_option scan_pipe: %ld outside -1..1", value);
+        h->opt_scan_pipe = (int)value;
+        return IVFHNSW_OK;
+    }
+    return fail(IVFHNSW_ERR_INVALID, "set_option: unknown key '%s'", key);
+}
+
 static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const ivfhnsw_search_params *p,
                             float *d_distances, int64_t *d_labels)
 {
@@ -1538,8 +1552,8 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     if (k == 1 && nq < 1024)
         nsplit = (int)std::min<size_t>(32, (2048 + nq - 1) / nq);
     // list shards: table and scan in one software-pipelined kernel, the table never leaves the chip (kernels_scan3.hip)
-    const bool pipe = k == 1 && !h->has_group && !heap &&
-                      scan_pipe_supported(h->t, max_seg, (int)nq, nsplit, h->n_local > 0);
+    const bool pipe = k == 1 && !h->has_group && !heap && h->opt_scan_pipe != 0 &&
+                      scan_pipe_supported(h->t, max_seg, (int)nq, nsplit, h->n_local > 0, h->opt_scan_pipe == 1);
     // one GPU, IVFADC: plan and tables are independent of each other and go in ONE launch (kernels_search.hip
     // plan_lut_kernel; IVFHNSW_PLAN_LUT=0 keeps them apart)
     static const bool plan_lut_on = [] {

@@ -146,7 +146,7 @@ hipError_t launch_scan(hipStream_t s, const IvfTables &t, const float *luts, con
                        // *did_select tells whether it did (else launch_select has to run)
                        float *sel_dist = nullptr, int64_t *sel_labels = nullptr, bool *did_select = nullptr); // expected codes per plan segment (0 = unknown): picks the scan form
 // table + scan pipelined over queries, for list shards (kernels_scan3.hip)
-bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes);
+bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes, bool forced = false);
 hipError_t launch_scan_pipe(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,
                             const PlanHdr *hdr, int max_seg, int nq, uint64_t *keys);
 // plan + table + scan + select of a small IVFADC batch in one launch (kernels_tail.hip); keys_inv [nq] and done [nq] zeroed

@@ -355,14 +355,14 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 // Used for list shards (shard_world >= 8) on the common shapes, whole batches, plans of at most 64 segments;
 // IVFHNSW_SCAN_PIPE = 1 forces it for a single shard too, 0 turns it off.
-bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes)
+bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bool has_codes, bool forced)
 {
     static const int knob = [] {
         const char *e = getenv("IVFHNSW_SCAN_PIPE");
         return (e && *e) ? (atoi(e) != 0 ? 1 : 0) : -1;
     }();
     (void)nsplit; // a workgroup takes whole queries: small batches simply launch fewer workgroups
-    if (knob == 0 || max_seg > PSEG || !has_codes || (knob != 1 && nq < 1024))
+    if (knob == 0 || max_seg > PSEG || !has_codes || (knob != 1 && !forced && nq < 1024))
         return false;
     const bool shape = (t.M == 16 && (t.dsub == 8 || t.dsub == 6)) || (t.M == 8 && (t.dsub == 16 || t.dsub == 12));
     if (!shape)
@@ -370,7 +370,7 @@ bool scan_pipe_supported(const IvfTables &t, int max_seg, int nq, int nsplit, bo
     // measured per rank (tools/rank_emulation.py, 1B corpus): at 2 and 4 shards lut_kernel + scan_k1_kernel win (0.48 vs 0.55,
     // 0.59 vs 0.63 ms: their eight workgroups per CU keep the LDS busier than two pipelined ones), at 8 the table traffic
     // has grown to where this form draws level (0.735 vs 0.745) and saves the 1.3-GB table buffer
-    return knob == 1 || t.shard_world >= 8;
+    return knob == 1 || forced || t.shard_world >= 8;
 }
 
 hipError_t launch_scan_pipe(hipStream_t s, const IvfTables &t, const float *xq, const Seg *segs, const uint32_t *lpos,

@@ -184,7 +184,7 @@ class ShardedSearcher:
     enters `torch.cuda.stream(s)` before constructing the searcher and around every step."""
 
     def __init__(self, gpu_index, rank, world, nq, nprobe, device, group=None, k=1, force_collectives=False,
-                 stream_cap=None):
+                 stream_cap=None, split=None, split_min=8192):
         import torch
         self.g, self.rank, self.world, self.nq, self.nprobe, self.group = gpu_index, rank, world, nq, nprobe, group
         self.k = k
@@ -202,6 +202,53 @@ class ShardedSearcher:
         self.cd = torch.empty((self.per * world, nprobe), dtype=torch.float32, device=device)
         self.keys = torch.empty((nq, k), dtype=torch.int64, device=device)
         self.xrot = None  # own slice of the batch, OPQ-rotated for the coarse walk (allocated on first use)
+        # Two overlapping parts (round 3): what the one-GPU call does inside ivfhnsw_gpu_search_dev -- the scan of the
+        # first part beside the walk of the second -- for the sharded step, where the library cannot do it (the coarse
+        # results cross the ranks in between).  The rank's slice of `per` queries is cut n1 | n2; part p's scan covers the
+        # world * n_p queries every rank walked in its part p; part 2 runs on a VIEW of the handle and a side stream.
+        # k = 1 only, equal slices only.  Measured per rank (tools/rank_emulation.py --split, 1B shape, collectives
+        # aside): 2 shards 1.92 -> 1.81 ms, 4 shards 2.06 -> 1.94, 8 shards 2.22 -> 2.07 (600 permille, two-kernel scan).
+        self.parts = None
+        if split is None:
+            split = 780 if world < 8 else 600
+        if (split and k == 1 and self.device.type == "cuda" and world > 1 and nq % world == 0 and self.per >= split_min
+                and hasattr(gpu_index, "view")):
+            per = self.per
+            n2 = ((per * (1000 - split) // 1000 + 1024) // 2048) * 2048
+            n2 = max(min(2048, per // 2), min(n2, per // 2))
+            n1 = per - n2
+            self.view = gpu_index.view()
+            self.side = torch.cuda.Stream(device=self.device)
+            self.view.set_stream(self.side.cuda_stream)
+            for h in (gpu_index, self.view):   # the pipelined table + scan kernel holds most of a CU's LDS: not beside a walk
+                h.set_option("scan_pipe", 0)
+            ar = torch.arange(world, device=device).view(world, 1) * per
+            self.parts = []
+            for h, n, off in ((gpu_index, n1, 0), (self.view, n2, n1)):
+                idx = (ar + off + torch.arange(n, device=device).view(1, n)).reshape(-1)   # rank-major rows of this part
+                self.parts.append(dict(h=h, n=n, off=off, idx=idx,
+                                       cid=torch.empty((n * world, nprobe), dtype=torch.int32, device=device),
+                                       cd=torch.empty((n * world, nprobe), dtype=torch.float32, device=device),
+                                       xrot=None))
+            self.keys_all = torch.empty((nq, 1), dtype=torch.int64, device=device)
+            self.dist_all = torch.empty((nq, 1), dtype=torch.float32, device=device)
+            self.lab_all = torch.empty((nq, 1), dtype=torch.int64, device=device)
+            self.idx_all = torch.cat([p["idx"] for p in self.parts])
+            a1 = n1 * world
+            for p, sl in zip(self.parts, (slice(0, a1), slice(a1, nq))):
+                p["keys"], p["dist"], p["lab"] = self.keys_all[sl], self.dist_all[sl], self.lab_all[sl]
+
+    def last_scan_counts(self):
+        """(codes, segments) this rank scored in the last step (both parts of a two-part step)."""
+        a, b = self.g.last_scan_counts()
+        if self.parts is not None:
+            a2, b2 = self.view.last_scan_counts()
+            a, b = a + a2, b + b2
+        return a, b
+
+    def handles(self):
+        """The shard's handle and, in two-part mode, the view its second part runs on."""
+        return [self.g] + ([self.view] if self.parts is not None else [])
 
     def coarse(self, d_q, efSearch):
         """This rank's slice of the coarse stage, then the all-gather: self.cid / self.cd hold the whole batch."""
@@ -231,6 +278,8 @@ class ShardedSearcher:
         if self.bound_stream is not None and torch.cuda.current_stream(self.device).cuda_stream != self.bound_stream:
             raise RuntimeError("ShardedSearcher.step on another torch stream than the one its handle is bound to: the "
                                "collectives would not be ordered behind the shard's kernels")
+        if self.parts is not None and not heap_order:
+            return self._step_two_parts(d_q, d_dist, d_lab, max_codes, efSearch, do_pruning)
         self.coarse(d_q, efSearch)
         heap = heap_order and k > 1
         g.search_dev(nq, k, d_q, d_dist, d_lab, self.nprobe, max_codes, d_coarse_ids=self.cid,
@@ -271,3 +320,44 @@ class ShardedSearcher:
         g.resolve_keys_dev(nq, k, self.keys, d_dist, d_lab)
         if self.collectives:
             _all_reduce(d_lab, dist.ReduceOp.MAX, self.group)
+
+    def _step_two_parts(self, d_q, d_dist, d_lab, max_codes, efSearch, do_pruning):
+        """The k = 1 step as two overlapping parts (see __init__).  Collectives are issued in one order on every rank:
+        part 1's all-gathers, part 2's, one MIN over all keys, one MAX over all labels."""
+        import torch
+        import torch.distributed as dist
+        S = torch.cuda.current_stream(self.device)
+        r, world = self.rank, self.world
+        fork = torch.cuda.Event()
+        fork.record(S)
+        self.side.wait_event(fork)
+        for p, stream in zip(self.parts, (S, self.side)):
+            with torch.cuda.stream(stream):
+                h, n = p["h"], p["n"]
+                q_p = d_q.index_select(0, p["idx"])                       # this part's queries of every rank, rank-major
+                if p["xrot"] is None:
+                    p["xrot"] = torch.empty((n, d_q.shape[1]), dtype=torch.float32, device=self.device)
+                own = q_p[r * n:(r + 1) * n]
+                h.rotate_dev(n, own, p["xrot"])
+                h.coarse_dev(n, p["xrot"], self.nprobe, efSearch, p["cid"][r * n:], p["cd"][r * n:])
+                _all_gather_rows(p["cid"], r, n, self.group)
+                _all_gather_rows(p["cd"], r, n, self.group)
+                h.search_dev(n * world, 1, q_p, p["dist"], p["lab"], self.nprobe, max_codes, d_coarse_ids=p["cid"],
+                             d_coarse_dists=p["cd"], do_pruning=do_pruning, d_out_keys=p["keys"])
+                p["q"] = q_p   # keep the gathered queries alive until the streams have met again
+        join = torch.cuda.Event()
+        join.record(self.side)
+        S.wait_event(join)
+        _all_reduce(self.keys_all, dist.ReduceOp.MIN, self.group)
+        merged = torch.cuda.Event()
+        merged.record(S)
+        self.side.wait_event(merged)
+        for p, stream in zip(self.parts, (S, self.side)):
+            with torch.cuda.stream(stream):
+                p["h"].resolve_keys_dev(p["n"] * world, 1, p["keys"], p["dist"], p["lab"])
+        join2 = torch.cuda.Event()
+        join2.record(self.side)
+        S.wait_event(join2)
+        _all_reduce(self.lab_all, dist.ReduceOp.MAX, self.group)
+        d_dist.index_copy_(0, self.idx_all, self.dist_all)
+        d_lab.index_copy_(0, self.idx_all, self.lab_all)

@@ -77,6 +77,25 @@ def main():
                 good = np.array_equal(np.sort(lab, 1), np.sort(ref_l, 1)) and bool((np.diff(dis, axis=1) >= 0).all())
             ok &= bool(good)
             notes.append("nsubc=%d k=%d heap=%s: %s" % (nsubc, k, heap, good))
+        # the k = 1 step as two overlapping parts (the handle + a view on a side stream): a batch whose slices reach split_min
+        nqb = 8192
+        qb = np.ascontiguousarray(np.tile(c["queries"], (nqb // nq + 1, 1))[:nqb] + np.float32(0.25) * (np.arange(nqb, dtype=np.float32)[:, None] % 7))
+        ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+        rdb, rlb, _, _, stb = ox.search_batch(qb, k=1, nthreads=4)
+        d_qb = torch.from_numpy(qb).to(dev)
+        ddb = torch.empty((nqb, 1), dtype=torch.float32, device=dev)
+        llb = torch.empty((nqb, 1), dtype=torch.int64, device=dev)
+        s2 = D.ShardedSearcher(g, rank, world, nqb, nprobe, dev, k=1, split_min=4096)
+        assert s2.parts is not None and [p["n"] for p in s2.parts] == [2048, 2048]
+        for _ in range(2):
+            s2.step(d_qb, ddb, llb, max_codes, ef, do_pruning=grouping)
+        torch.cuda.synchronize()
+        good = np.array_equal(llb.cpu().numpy(), rlb) and np.array_equal(ddb.cpu().numpy().view(np.uint32), rdb.view(np.uint32))
+        tot = torch.tensor([float(s2.last_scan_counts()[0])], dtype=torch.float64)
+        dist.all_reduce(tot)
+        good = good and int(tot.item()) == stb.ncode    # the shards' two parts partition the scanned codes exactly
+        ok &= bool(good)
+        notes.append("nsubc=%d two-part step: %s" % (nsubc, good))
         # a step on another torch stream than the bound one must be refused, not silently mis-ordered
         other = torch.cuda.Stream(device=dev)
         try:

@@ -41,7 +41,7 @@ def test_sharded_searcher_two_ranks_on_the_gpu(tmp_path):
         assert p.returncode == 0, "rank %d exited %d:\n%s" % (r, p.returncode, outs[r][-3000:])
         f = tmp_path / ("rank%d.ok" % r)
         assert f.exists(), "rank %d: %s" % (r, (tmp_path / ("rank%d.fail" % r)).read_text())
-        assert f.read_text().count(": True") == 6
+        assert f.read_text().count(": True") == 8
 
 
 def test_bench_starts_its_own_ranks(tmp_path):

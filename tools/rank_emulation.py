@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--partition", choices=("spatial", "mod"), default="mod")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--split", type=int, default=0, help="permille of the rank's slice in the first of two parts on two "
+                    "streams (0 = one part): what a two-part sharded step would overlap, collectives aside")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -62,6 +64,38 @@ def main():
                      do_pruning=grouping)
         g.resolve_keys_dev(nq, 1, kk, dd, ll)
 
+    if args.split:
+        # two-part form: the own slice as n1 | n2 queries; part p's scan covers the W * n_p queries every rank walked in its
+        # part p (here: the first W * n1 and the last W * n2 of the batch), part 2 on a view and a second stream
+        n2 = max(2048 // 1, ((hi - lo) * (1000 - args.split) // 1000 + 1024) // 2048 * 2048)
+        n1 = (hi - lo) - n2
+        v = g.view()
+        st2 = torch.cuda.Stream(device=dev)
+        v.set_stream(st2.cuda_stream)
+        s0 = torch.cuda.current_stream()
+        dd2, ll2, kk2 = torch.empty_like(dd), torch.empty_like(ll), torch.empty_like(kk)
+        own_c2, own_d2 = torch.empty_like(own_c), torch.empty_like(own_d)
+        a1, a2 = W * n1, W * n2
+
+        def step():  # noqa: F811
+            ev = torch.cuda.Event()
+            ev.record(s0)
+            st2.wait_event(ev)
+            g.rotate_dev(n1, d_q[lo:lo + n1], xr[lo:lo + n1])
+            g.coarse_dev(n1, xr[lo:lo + n1], nprobe, ef, own_c, own_d)
+            g.search_dev(a1, 1, d_q[:a1], dd[:a1], ll[:a1], nprobe, max_codes, d_coarse_ids=cid[:a1], d_coarse_dists=cd[:a1],
+                         d_out_keys=kk[:a1], do_pruning=grouping)
+            with torch.cuda.stream(st2):
+                v.rotate_dev(n2, d_q[lo + n1:hi], xr[lo + n1:hi])
+                v.coarse_dev(n2, xr[lo + n1:hi], nprobe, ef, own_c2, own_d2)
+                v.search_dev(a2, 1, d_q[a1:], dd2[:a2], ll2[:a2], nprobe, max_codes, d_coarse_ids=cid[a1:],
+                             d_coarse_dists=cd[a1:], d_out_keys=kk2[:a2], do_pruning=grouping)
+                v.resolve_keys_dev(a2, 1, kk2[:a2], dd2[:a2], ll2[:a2])
+                e2 = torch.cuda.Event()
+                e2.record(st2)
+            g.resolve_keys_dev(a1, 1, kk[:a1], dd[:a1], ll[:a1])
+            s0.wait_event(e2)
+
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -74,6 +108,9 @@ def main():
     t = (time.perf_counter() - t0) / args.steps
     st = {a: round(b[0] / args.steps, 3) for a, b in g.stage_ms().items()}
     here = g.last_scan_counts()[0]
+    if args.split:
+        print("world %d rank %d two-part step (%d | %d of the own slice): %.3f ms per step of %d queries" % (W, r, n1, n2, t * 1e3, nq))
+        return
     # every rank's scored codes from the plan rule on the host (IVFADC rule; Grouping prunes inside lists, same shares)
     bal = ""
     if not grouping:
