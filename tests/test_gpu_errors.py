@@ -96,3 +96,25 @@ def test_large_batch_is_chunked(gpu):
     assert np.array_equal(lab.reshape(-1)[:32 * (n // 32)].reshape(-1, 32), np.tile(l0.reshape(1, 32), (n // 32, 1)))
     assert np.array_equal(dist[-777 % 32 or None:][:0], dist[:0])  # shape sanity
     assert lab[-1, 0] == l0[(n - 1) % 32, 0] and dist[-1, 0] == d0[(n - 1) % 32, 0]
+
+
+def test_options_and_neighbour_table_arguments_are_checked(gpu, pkg):
+    g = gpu()
+    g.set_option("scan_pipe", 0)
+    g.set_option("scan_pipe", -1)
+    with pytest.raises(pkg.IvfHnswError) as e:
+        g.set_option("scan_pipe", 2)
+    assert e.value.code == pkg.ERR_INVALID
+    with pytest.raises(pkg.IvfHnswError) as e:
+        g.set_option("no_such_option", 1)
+    assert e.value.code == pkg.ERR_INVALID and "unknown key" in str(e.value)
+    x = np.zeros((40, 128), np.float32)
+    with pytest.raises(pkg.IvfHnswError):
+        g.knn(x, 4, mode=3)
+    with pytest.raises(pkg.IvfHnswError):
+        g.build_graph(x, M=16, maxM=8)          # M > maxM
+    with pytest.raises(pkg.IvfHnswError):
+        g.build_graph(x, M=16, maxM=32, ncand=100)
+    # the handle is still usable
+    ids, _ = g.knn(x + np.arange(40, dtype=np.float32)[:, None], 3)
+    assert ids.shape == (40, 3)

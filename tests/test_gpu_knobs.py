@@ -63,6 +63,9 @@ def test_every_knob_setting_reproduces_the_default_path():
                 {"IVFHNSW_WALK_LATE_VISIT": "1", "IVFHNSW_WALK_TAGW": "16"}, {"IVFHNSW_WALK_LATE_VISIT": "0"},
                 {"IVFHNSW_TAIL": "0"},               # small batches through the four separate launches
                 {"IVFHNSW_PLAN_GROUP4": "0"},        # Grouping plan by one wavefront per query (default: four)
+                {"IVFHNSW_PLAN_DEDUPE": "1"},        # ... every distinct neighbour centroid once, through the LDS hash set
+                {"IVFHNSW_PLAN_DEDUPE": "0"},        # ... every (row, sub-group) pair's row gathered
+                {"IVFHNSW_SPLIT": "0"},              # large batches in one part (default: two parts on two streams)
                 {"IVFHNSW_PLAN_LUT": "0"},           # plan and tables as two launches (default: one, plan_lut_kernel)
                 {"IVFHNSW_SCAN_PIPE": "1"}):         # table + scan pipelined over queries (kernels_scan3.hip), one shard too
         assert _run(env) == base, env
