@@ -460,6 +460,8 @@ def main():
                    "ms_per_step": round(el2 / args.steps * 1e3, 4),
                    "note": "every group holds the whole corpus in %d list shard(s) and serves its own batch; collectives "
                            "stay inside the group" % S2}
+        if sh2 is not None:
+            sh2.close()
         g2.close()
         g.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -823,6 +825,8 @@ def main():
             gr_.close()
         print(json.dumps(out), flush=True)
 
+    if sharded is not None:
+        sharded.close()
     g.close()
     if world > 1:
         dist.destroy_process_group()

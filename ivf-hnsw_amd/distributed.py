@@ -246,6 +246,12 @@ class ShardedSearcher:
             a, b = a + a2, b + b2
         return a, b
 
+    def close(self):
+        """Release the view the two-part step runs its second part on (the shard's own handle stays the caller's)."""
+        if self.parts is not None:
+            self.view.close()
+            self.parts = None
+
     def handles(self):
         """The shard's handle and, in two-part mode, the view its second part runs on."""
         return [self.g] + ([self.view] if self.parts is not None else [])

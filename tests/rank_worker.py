@@ -96,6 +96,7 @@ def main():
         good = good and int(tot.item()) == stb.ncode    # the shards' two parts partition the scanned codes exactly
         ok &= bool(good)
         notes.append("nsubc=%d two-part step: %s" % (nsubc, good))
+        s2.close()
         # a step on another torch stream than the bound one must be refused, not silently mis-ordered
         other = torch.cuda.Stream(device=dev)
         try:

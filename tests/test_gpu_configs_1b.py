@@ -27,7 +27,11 @@ NTHREADS = 16
 
 def _tables(seed, nc, d, kind):
     tb = synth.make_throughput_tables(seed, nc, d, 16, N1B, kind=kind)
-    counts, links = synth.knn_graph_torch(tb["centroids"], 16, 32)
+    # the coarse graph as the bench builds it: hnswlib's insertion loop with exact candidates, on the device
+    import __graft_entry__ as ge
+    gb = ge.load_pkg().GpuIndex(0)
+    counts, links = gb.build_graph(tb["centroids"], 16, 32, 64)
+    gb.close()
     cn = (tb["centroids"].astype(np.float64) ** 2).sum(1).astype(np.float32)
     tb.update(counts=counts, links=links, centroid_norms=cn, code_seed=seed + 7)
     return tb
