@@ -201,6 +201,17 @@ int ivfhnsw_gpu_resolve_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t 
 int ivfhnsw_gpu_last_stream(ivfhnsw_gpu *h, size_t nq, size_t len_cap, uint64_t *keys, uint32_t *lens,
                             uint32_t *stream_cap);
 
+/* The whole shard step for a caller that holds the N shard handles of one index in ONE process (north_star: "per-shard
+ * top-k merged over RCCL/xGMI" under C++ host code): every shard scans its lists for the batch (the coarse stage is
+ * supplied: it is computed once, IndexIVF_HNSW::search2's split, IndexIVF_HNSW.cpp:453-492), the packed keys are
+ * MIN-merged across the shards' devices with one RCCL all-reduce (ncclInt64 / ncclMin; RCCL is loaded on first use), each
+ * shard resolves the labels it owns, one more all-reduce (ncclMax) merges them, and shard 0's device returns distances
+ * and labels.  k = 1, or k > 1 ascending (heap_order = 0).  Shards that share a device (a one-GPU box) or k > 1: the same
+ * step with the merge on the host.  Host pointers; at most 131 072 queries per call. */
+int ivfhnsw_gpu_search_sharded(ivfhnsw_gpu *const *shards, size_t nshards, size_t nq, size_t k, const float *queries,
+                               const uint32_t *coarse_ids, const float *coarse_dists, const ivfhnsw_search_params *params,
+                               float *distances, int64_t *labels);
+
 /* The coarse stage alone (HierarchicalNSW::searchKnn, hnswalg.cpp:227-234, plus the unload loop of
  * IndexIVF_HNSW.cpp:249-259): device pointers, [nq*nprobe] outputs, nearest first.  Queries must
  * already be rotated when OPQ is on. */

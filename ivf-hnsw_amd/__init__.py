@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
     "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
-    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph", "ivfhnsw_gpu_set_option",
+    "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph", "ivfhnsw_gpu_set_option", "ivfhnsw_gpu_search_sharded",
 )
 
 
@@ -114,6 +114,8 @@ def lib():
         L.ivfhnsw_gpu_knn_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_int, C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+        L.ivfhnsw_gpu_search_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.POINTER(SearchParams), C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_set_batch_split.argtypes = [C.c_void_p, C.c_int]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
@@ -144,6 +146,23 @@ def _devptr(t):
         return C.c_void_p(t)
     assert t.is_cuda and t.is_contiguous()
     return C.c_void_p(t.data_ptr())
+
+
+def search_sharded(shards, queries, k, nprobe, max_codes, coarse_ids, coarse_dists, do_pruning=False):
+    """ivfhnsw_gpu_search_sharded: the shard step over all shard handles of one process (RCCL merge across devices, host
+    merge when they share one); host arrays in and out."""
+    q = _np(queries, np.float32)
+    q = q.reshape(-1, q.shape[-1])
+    nq = q.shape[0]
+    cid = _np(coarse_ids, np.uint32).reshape(nq, nprobe)
+    cd = _np(coarse_dists, np.float32).reshape(nq, nprobe)
+    dist = np.empty((nq, k), np.float32)
+    lab = np.empty((nq, k), np.int64)
+    arr = (C.c_void_p * len(shards))(*[g._h for g in shards])
+    p = SearchParams(nprobe, max_codes, 0, 1 if do_pruning else 0, 0)
+    _check(lib().ivfhnsw_gpu_search_sharded(arr, len(shards), nq, k, _ptr(q), _ptr(cid), _ptr(cd), C.byref(p), _ptr(dist),
+                                            _ptr(lab)))
+    return dist, lab
 
 
 class GpuIndex:

@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enum values only: the library itself is dlopen'ed on first use (no link dependency)
+#include <map>
 #include <string>
 #include <vector>
 
@@ -1812,6 +1815,211 @@ int ivfhnsw_gpu_search_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const float *qu
     HIP_TRY(hipMemcpyAsync(keys, h->s_keys.p, nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return check_status(h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The shard step for a caller that holds all N shard handles in ONE process (the bundled classes with IVFHNSW_SHARDS=N):
+// every shard scans its lists for the whole batch, the packed keys are MIN-merged ACROSS THE DEVICES over RCCL (xGMI) and
+// the owner's labels MAX-merged, without the keys ever visiting the host.  RCCL is loaded on first use (dlopen: the
+// library has no link-time dependency on it) and one communicator per device list is kept for the life of the process
+// (ncclCommInitAll).  Shards that share a device -- a one-GPU box -- cannot form a communicator (RCCL refuses two ranks
+// on one device): the same step then merges on the host, which is what the classes did before round 3.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.lib)
+                break;
+        }
+        if (x.lib) {
+            x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(dlsym(x.lib, "ncclCommInitAll"));
+            x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.lib, "ncclAllReduce"));
+            x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.lib, "ncclGroupStart"));
+            x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.lib, "ncclGroupEnd"));
+            x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.lib, "ncclGetErrorString"));
+            x.ok = x.CommInitAll && x.AllReduce && x.GroupStart && x.GroupEnd;
+        }
+        return x;
+    }();
+    return r;
+}
+
+// one communicator set per device list, created once (ncclCommInitAll is collective over the devices of this process)
+std::vector<ncclComm_t> *rccl_comms(const std::vector<int> &devs)
+{
+    static std::map<std::vector<int>, std::vector<ncclComm_t>> cache;
+    auto it = cache.find(devs);
+    if (it != cache.end())
+        return it->second.empty() ? nullptr : &it->second;
+    std::vector<ncclComm_t> comms(devs.size(), nullptr);
+    Rccl &r = rccl();
+    if (!r.ok || r.CommInitAll(comms.data(), (int)devs.size(), devs.data()) != ncclSuccess)
+        comms.clear();
+    auto &slot = cache[devs] = comms;
+    return slot.empty() ? nullptr : &slot;
+}
+
+} // namespace
+} // extern "C++"
+
+int ivfhnsw_gpu_search_sharded(ivfhnsw_gpu *const *shards, size_t nshards, size_t nq, size_t k, const float *queries,
+                               const uint32_t *coarse_ids, const float *coarse_dists, const ivfhnsw_search_params *p,
+                               float *distances, int64_t *labels)
+{
+    if (!shards || nshards == 0 || nshards > 64)
+        return fail(IVFHNSW_ERR_INVALID, "search_sharded: 1..64 shard handles");
+    for (size_t r = 0; r < nshards; r++)
+        if (!shards[r] || !shards[r]->has_ivf)
+            return fail(IVFHNSW_ERR_STATE, "search_sharded: shard %zu has no index", r);
+    if (!p || p->nprobe == 0 || k == 0)
+        return fail(IVFHNSW_ERR_INVALID, "nprobe and k must be positive");
+    if (p->heap_order && k > 1)
+        return fail(IVFHNSW_ERR_INVALID, "search_sharded merges keys (k = 1, or k > 1 ascending); the heap-array order of "
+                                         "k > 1 needs the candidate streams (ivfhnsw_gpu_last_stream)");
+    if (nq == 0)
+        return IVFHNSW_OK;
+    if (!queries || !coarse_ids || !coarse_dists || !distances || !labels)
+        return fail(IVFHNSW_ERR_INVALID, "null buffer (the coarse stage is computed once and supplied)");
+    if (nq > kMaxBatchAll)
+        return fail(IVFHNSW_ERR_INVALID, "search_sharded is limited to %zu queries per call", kMaxBatchAll);
+    const size_t d = shards[0]->t.d, np = p->nprobe, nk = nq * k;
+    int rc;
+    // 1. every shard: inputs to its device, scan of its lists, keys left on the device (asynchronous, one stream each)
+    for (size_t r = 0; r < nshards; r++) {
+        ivfhnsw_gpu *h = shards[r];
+        if ((rc = bind(h)))
+            return rc;
+        if ((rc = h->s_q.ensure(nq * d * sizeof(float))) || (rc = h->s_dist.ensure(nk * sizeof(float))) ||
+            (rc = h->s_lab.ensure(nk * sizeof(int64_t))) || (rc = h->s_keys.ensure(nk * sizeof(int64_t))) ||
+            (rc = h->s_cid.ensure(nq * np * sizeof(uint32_t))) || (rc = h->s_cd.ensure(nq * np * sizeof(float))))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(h->s_q.p, queries, nq * d * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_cid.p, coarse_ids, nq * np * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_cd.p, coarse_dists, nq * np * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if ((rc = ivfhnsw_gpu_search_dev(h, nq, k, h->s_q.as<float>(), h->s_cid.as<uint32_t>(), h->s_cd.as<float>(), p,
+                                         h->s_dist.as<float>(), h->s_lab.as<int64_t>(), h->s_keys.as<int64_t>())))
+            return rc;
+    }
+    // 2. the merge.  Over RCCL when every shard has a device of its own (or, for the single shard of a test, when
+    // IVFHNSW_SHARDS_RCCL=1 asks for the calls to be made anyway); k = 1: one int64 MIN of the keys, one MAX of the labels
+    std::vector<int> devs(nshards);
+    bool distinct = true;
+    for (size_t r = 0; r < nshards; r++) {
+        devs[r] = shards[r]->device;
+        for (size_t q = 0; q < r; q++)
+            distinct = distinct && devs[q] != devs[r];
+    }
+    static const int force = [] {
+        const char *e = getenv("IVFHNSW_SHARDS_RCCL");
+        return (e && *e) ? atoi(e) : -1;
+    }();
+    std::vector<ncclComm_t> *comms = nullptr;
+    if (k == 1 && distinct && force != 0 && (nshards > 1 || force == 1))
+        comms = rccl_comms(devs);
+    if (comms) {
+        Rccl &R = rccl();
+        auto all_reduce = [&](bool labels_pass) -> int {
+            ncclResult_t e = R.GroupStart();
+            for (size_t r = 0; r < nshards && e == ncclSuccess; r++) {
+                ivfhnsw_gpu *h = shards[r];
+                (void)hipSetDevice(h->device);
+                void *buf = labels_pass ? h->s_lab.p : h->s_keys.p;
+                e = R.AllReduce(buf, buf, nk, ncclInt64, labels_pass ? ncclMax : ncclMin, (*comms)[r], h->stream);
+            }
+            const ncclResult_t e2 = R.GroupEnd();
+            return (int)(e != ncclSuccess ? e : e2);
+        };
+        int e = all_reduce(false);
+        if (e)
+            return fail(IVFHNSW_ERR_HIP, "RCCL all-reduce (MIN of the keys) failed: %s", R.GetErrorString ? R.GetErrorString((ncclResult_t)e) : "?");
+        for (size_t r = 0; r < nshards; r++) {
+            ivfhnsw_gpu *h = shards[r];
+            if ((rc = ivfhnsw_gpu_resolve_keys_dev(h, nq, k, h->s_keys.as<int64_t>(), h->s_dist.as<float>(), h->s_lab.as<int64_t>())))
+                return rc;
+        }
+        if ((e = all_reduce(true)))
+            return fail(IVFHNSW_ERR_HIP, "RCCL all-reduce (MAX of the labels) failed: %s", R.GetErrorString ? R.GetErrorString((ncclResult_t)e) : "?");
+        ivfhnsw_gpu *h0 = shards[0];
+        if ((rc = bind(h0)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(distances, h0->s_dist.p, nk * sizeof(float), hipMemcpyDeviceToHost, h0->stream));
+        HIP_TRY(hipMemcpyAsync(labels, h0->s_lab.p, nk * sizeof(int64_t), hipMemcpyDeviceToHost, h0->stream));
+        for (size_t r = 0; r < nshards; r++) {
+            if ((rc = bind(shards[r])))
+                return rc;
+            HIP_TRY(hipStreamSynchronize(shards[r]->stream));
+            if ((rc = check_status(shards[r])))
+                return rc;
+        }
+        return IVFHNSW_OK;
+    }
+    // ... on the host otherwise (shards sharing a device, k > 1): the k smallest keys per query over the shards
+    std::vector<std::vector<int64_t>> keys(nshards, std::vector<int64_t>(nk));
+    for (size_t r = 0; r < nshards; r++) {
+        ivfhnsw_gpu *h = shards[r];
+        if ((rc = bind(h)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(keys[r].data(), h->s_keys.p, nk * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    for (size_t r = 0; r < nshards; r++) {
+        if ((rc = bind(shards[r])))
+            return rc;
+        HIP_TRY(hipStreamSynchronize(shards[r]->stream));
+        if ((rc = check_status(shards[r])))
+            return rc;
+    }
+    std::vector<int64_t> merged(nk);
+    std::vector<int64_t> pool(nshards * k);
+    for (size_t i = 0; i < nq; i++) {
+        if (k == 1) {
+            int64_t m = keys[0][i];
+            for (size_t r = 1; r < nshards; r++)
+                m = keys[r][i] < m ? keys[r][i] : m;
+            merged[i] = m;
+        } else {
+            for (size_t r = 0; r < nshards; r++)
+                std::copy(keys[r].begin() + i * k, keys[r].begin() + (i + 1) * k, pool.begin() + r * k);
+            std::partial_sort(pool.begin(), pool.begin() + k, pool.end());
+            std::copy(pool.begin(), pool.begin() + k, merged.begin() + i * k);
+        }
+    }
+    std::vector<int64_t> lab(nk);
+    for (size_t r = 0; r < nshards; r++) {
+        ivfhnsw_gpu *h = shards[r];
+        if ((rc = bind(h)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(h->s_keys.p, merged.data(), nk * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        if ((rc = ivfhnsw_gpu_resolve_keys_dev(h, nq, k, h->s_keys.as<int64_t>(), h->s_dist.as<float>(), h->s_lab.as<int64_t>())))
+            return rc;
+    }
+    for (size_t r = 0; r < nshards; r++) {
+        ivfhnsw_gpu *h = shards[r];
+        if ((rc = bind(h)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(lab.data(), h->s_lab.p, nk * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        if (r == 0)
+            HIP_TRY(hipMemcpyAsync(distances, h->s_dist.p, nk * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < nk; i++)
+            labels[i] = (r == 0 || lab[i] > labels[i]) ? lab[i] : labels[i];
+    }
+    return IVFHNSW_OK;
 }
 
 int ivfhnsw_gpu_resolve_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *keys, float *distances, int64_t *labels)

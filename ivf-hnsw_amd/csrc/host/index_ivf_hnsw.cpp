@@ -361,6 +361,17 @@ void IndexIVF_HNSW::device_search(size_t nq, size_t k, const float *x, const idx
     }
     const bool heap = k > 1;
     p.heap_order = heap ? 1 : 0;
+    if (!heap) {
+        // k = 1 (every preset of the reference): the whole shard step below the C ABI -- scans on the shards' devices, the
+        // keys MIN-merged and the labels MAX-merged over RCCL between the devices (on the host when shards share a device)
+        std::vector<ivfhnsw_gpu *> hs(world);
+        for (size_t r = 0; r < world; r++)
+            hs[r] = shard(r);
+        if (ivfhnsw_gpu_search_sharded(hs.data(), world, nq, k, x, coarse_ids, coarse_dists, &p, distances,
+                                       reinterpret_cast<int64_t *>(labels)))
+            gpu_fail("ivfhnsw_gpu_search_sharded");
+        return;
+    }
     std::vector<std::vector<int64_t>> keys(world, std::vector<int64_t>(nq * k));
     std::vector<std::string> err(world);
     // one host thread per shard: every handle has its own device and stream

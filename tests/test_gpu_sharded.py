@@ -266,3 +266,72 @@ def test_sharded_pipelined_scan(gpu, pkg, world, d, M):
         label = torch.maximum(label, ll)
     assert np.array_equal(label.cpu().numpy(), ref_l)
     assert np.array_equal(dd.cpu().numpy().view(np.uint32), ref_d.view(np.uint32))
+
+
+@pytest.mark.parametrize("grouping", [False, True])
+def test_search_sharded_entry_point(gpu, pkg, grouping):
+    """ivfhnsw_gpu_search_sharded: the whole shard step for one process holding all shard handles (what the bundled classes
+    call with IVFHNSW_SHARDS=N).  Three shards on the one GPU share a device, so the keys are merged on the host here; on a
+    node with a device per shard the same call merges them with RCCL all-reduces (ncclMin / ncclMax)."""
+    if grouping:
+        c = corpus(seed=41, nc=256, d=128, M=16, n_base=30000, nq=96, nsubc=16)
+    else:
+        c = corpus(seed=11, nc=256, d=128, M=16, n_base=30000, nq=128)
+    nprobe, max_codes, ef, world = 16, 2500, 40, 3
+    ox = synth.oracle_index(c)
+    ox.set_params(nprobe, max_codes, ef, do_pruning=grouping)
+    owner = _owner_table(pkg, c, world, "spatial")
+    gr = c["graph"]
+    shards = []
+    for r in range(world):
+        g = gpu()
+        ids, codes, ncodes = _shard_arrays(c, r, world, owner)
+        g.upload_ivf(c["d"], c["code_size"], c["offsets"], ids, codes, ncodes, c["centroid_norms"], c["pq_centroids"],
+                     c["norm_table"], shard_rank=r, shard_world=world, list_owner=owner)
+        if grouping:
+            g.upload_grouping(c["nsubc"], c["alphas"], c["nn_centroid_idxs"], c["subgroup_sizes"], c["inter_centroid_dists"])
+            g.upload_quantizer(gr.counts, gr.links, gr.vectors, gr.enterpoint)
+        shards.append(g)
+    for k in (1, 7):
+        ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=k)
+        dist, lab = pkg.search_sharded(shards, c["queries"], k, nprobe, max_codes, cid, cd, do_pruning=grouping)
+        if k == 1:
+            assert np.array_equal(lab, ref_l) and np.array_equal(dist.view(np.uint32), ref_d.view(np.uint32))
+        else:   # the reference's result set, ascending
+            assert np.array_equal(np.sort(lab, 1), np.sort(ref_l, 1)) and (np.diff(dist, axis=1) >= 0).all()
+
+
+def test_search_sharded_makes_the_rccl_calls(tmp_path):
+    """A single shard with IVFHNSW_SHARDS_RCCL=1: ncclCommInitAll over one device and the two all-reduces (int64 MIN of the
+    keys, MAX of the labels) are EXECUTED -- dtype, reduction, in-place buffers, group calls -- with results checked; what one
+    GPU cannot show is the exchange between devices."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import numpy as np
+import __graft_entry__ as ge
+import synth
+pkg = ge.load_pkg()
+c = synth.make_corpus(seed=13, nc=128, d=96, M=8, n_base=9000, nq=70, efConstruction=60)
+ox = synth.oracle_index(c)
+ox.set_params(8, 1500, 32)
+ref_d, ref_l, cid, cd, _ = ox.search_batch(c["queries"], k=1)
+g = pkg.GpuIndex(0)
+g.upload_ivf(c["d"], c["code_size"], c["offsets"], c["ids"], c["codes"], c["norm_codes"], c["centroid_norms"],
+             c["pq_centroids"], c["norm_table"])
+dist, lab = pkg.search_sharded([g], c["queries"], 1, 8, 1500, cid, cd)
+assert np.array_equal(lab, ref_l) and np.array_equal(dist.view(np.uint32), ref_d.view(np.uint32))
+print("RCCL_SHARDED_OK")
+""" % (root, root)
+    env = dict(os.environ, IVFHNSW_SHARDS_RCCL="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL_SHARDED_OK" in r.stdout, r.stderr[-3000:] + r.stdout[-500:]
+    # the communicator really came from RCCL (the library logs nothing by default: ask it)
+    env["NCCL_DEBUG"] = "VERSION"
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL" in (r.stdout + r.stderr).upper()
