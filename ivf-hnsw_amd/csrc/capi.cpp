@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h> // types and enum values only: the library itself is dlopen'ed on first use (no link dependency)
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1864,6 +1865,8 @@ Rccl &rccl()
 std::vector<ncclComm_t> *rccl_comms(const std::vector<int> &devs)
 {
     static std::map<std::vector<int>, std::vector<ncclComm_t>> cache;
+    static std::mutex mu;   // handles are one-thread-at-a-time objects, this table is process-wide
+    std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(devs);
     if (it != cache.end())
         return it->second.empty() ? nullptr : &it->second;
