@@ -476,10 +476,11 @@ def main():
         host_qps = 3 * nq / (time.perf_counter() - t_h)
 
     # `value` is what a plain search_dev call delivers: since round 3 a batch of >= 8192 queries runs as two uneven parts on
-    # two streams inside the call (ivfhnsw_gpu_set_batch_split, default 780 permille in the first part).  Reported beside
+    # two streams inside the call (ivfhnsw_gpu_set_batch_split; the parts' sizes follow the call's parameters).  Reported beside
     # it, never as it: the same batch in ONE part (IVFHNSW_SPLIT=0) -- one launch per kernel, the shape rounds 1-2 measured
     # and the one the scan's rate reads best on.
     one_part = None
+    parts_used = g.last_batch_parts() if world == 1 else (nq, 0)
     split_active = world == 1 and nq >= 8192 and os.environ.get("IVFHNSW_SPLIT", "") != "0" and not args.no_split
     if split_active and not args.no_one_part:
         g.set_batch_split(0)
@@ -503,7 +504,7 @@ def main():
         torch.cuda.synchronize()
         st1_all = g.stage_ms()
         g.set_profiling(False)
-        g.set_batch_split(780)
+        g.set_batch_split(int(os.environ.get("IVFHNSW_SPLIT", "") or 1000))
         r1 = scan_roofline(g, M, st1, None, n_sp)
         one_part = {"steps": n_sp, "queries_per_s": round(nq * n_sp / el_sp, 1), "ms_per_batch": round(el_sp / n_sp * 1e3, 4),
                     "scan_avg_launch_ms": r1["avg_launch_ms"], "scan_gbps": r1["achieved"], "scan_frac_of_hbm_peak": r1["frac"],
@@ -619,7 +620,7 @@ def main():
                           "event pairs per step cost 2.3 %% of it)" % n_aux,
             "host_pointer_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "pipelined": pipe,
-            "batch_split": {"parts": 2 if split_active else 1, "first_part_permille": 780 if split_active else None,
+            "batch_split": {"parts": 2 if split_active else 1, "part_queries": list(parts_used) if split_active else None,
                             "note": "a plain ivfhnsw_gpu_search_dev call of >= 8192 queries runs as two uneven parts on two "
                                     "streams (default since ABI 9; IVFHNSW_SPLIT=0 = one part): `value`, `roofline` "
                                     "(17 B x ALL codes of the step over the SUMMED scan-launch time) and the stage "

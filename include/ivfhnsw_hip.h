@@ -116,13 +116,17 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
 int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h);
 
 /* Large batches as two uneven parts on two streams inside ivfhnsw_gpu_search[_dev] (a batched extension; the reference
- * searches one query per call, IndexIVF_HNSW.cpp:232-293).  permille = share of the batch in the first part; 780, the
- * default since ABI 9, is what measured best (1.81 -> 1.67 ms per 10 k queries at the 1B shape); 0 = one part (also set
- * by the environment variable IVFHNSW_SPLIT at ivfhnsw_gpu_create).  The second part runs on an internal view of the handle;
+ * searches one query per call, IndexIVF_HNSW.cpp:232-293).  permille = share of the batch in the first part, 1..999;
+ * 1000, the default since ABI 9, = chosen per call from its own parameters (the walk's time against table + plan + scan:
+ * 0.79 at (32, 10000, 80), 1.81 -> 1.67 ms per 10 k queries at the 1B shape; 0.63 at (64, 30000, 100); 0.49 for Grouping);
+ * 0 = one part (the environment variable IVFHNSW_SPLIT sets the same at ivfhnsw_gpu_create).  The second part is a whole
+ * number of 2048-query rounds, at most half the batch, and runs on an internal view of the handle;
  * its walk fills the tail of the first part's, the first part's table + scan run beside it.  Results, ordering behind
  * the handle's stream and error reporting are those of the unsplit call.  Applies to calls of >= 8192 queries without
  * given coarse results, out_keys or heap-order k > 1. */
 int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille);
+/* The queries in the two parts of the last search[_dev] call (second = 0: it ran in one part). */
+int ivfhnsw_gpu_last_batch_parts(ivfhnsw_gpu *h, uint64_t *first, uint64_t *second);
 
 /* Options of this library (nothing of the reference's: its knobs are public members, below).  Unknown keys are refused.
  *   "scan_pipe"  -1 (default) the library chooses, 0 never, 1 wherever the shape allows: table + scan of a list shard as

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "ivfhnsw_gpu_memory_bytes", "ivfhnsw_gpu_upload_codebooks", "ivfhnsw_gpu_encode",
     "ivfhnsw_gpu_encode_groups", "ivfhnsw_gpu_rotate_dev", "ivfhnsw_gpu_last_scan_kernel",
     "ivfhnsw_gpu_last_stream_dev", "ivfhnsw_gpu_replay_stream_dev", "ivfhnsw_gpu_pq_train", "ivfhnsw_gpu_xty",
-    "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
+    "ivfhnsw_gpu_prepare_latency", "ivfhnsw_gpu_set_batch_split", "ivfhnsw_gpu_last_batch_parts", "ivfhnsw_gpu_search_keys", "ivfhnsw_gpu_resolve_keys", "ivfhnsw_gpu_last_stream",
     "ivfhnsw_gpu_device_count", "ivfhnsw_gpu_knn", "ivfhnsw_gpu_knn_dev", "ivfhnsw_gpu_build_graph", "ivfhnsw_gpu_set_option", "ivfhnsw_gpu_search_sharded",
 )
 
@@ -118,6 +118,7 @@ def lib():
                                                  C.c_void_p, C.c_void_p, C.POINTER(SearchParams), C.c_void_p, C.c_void_p]
         L.ivfhnsw_gpu_prepare_latency.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_set_batch_split.argtypes = [C.c_void_p, C.c_int]
+        L.ivfhnsw_gpu_last_batch_parts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ivfhnsw_gpu_last_scan_kernel.argtypes = [C.c_void_p]
         L.ivfhnsw_gpu_last_scan_kernel.restype = C.c_char_p
         _lib = L
@@ -251,8 +252,15 @@ class GpuIndex:
         _check(lib().ivfhnsw_gpu_prepare_latency(self._h))
 
     def set_batch_split(self, permille):
-        """Batches of >= 8192 queries as two uneven parts on two streams (ivfhnsw_gpu_set_batch_split); 0 = off."""
+        """Batches of >= 8192 queries as two uneven parts on two streams (ivfhnsw_gpu_set_batch_split); 0 = off,
+        1..999 = the first part's share, 1000 = chosen per call (the default)."""
         _check(lib().ivfhnsw_gpu_set_batch_split(self._h, int(permille)))
+
+    def last_batch_parts(self):
+        """(first, second): queries in the two parts of the last search call; second = 0 when it ran in one part."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().ivfhnsw_gpu_last_batch_parts(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- search --------------------------------------------------------------------------------
     @staticmethod

@@ -133,6 +133,7 @@ struct ivfhnsw_gpu {
     ivfhnsw_gpu *split_view = nullptr;
     hipEvent_t split_fork = nullptr, split_join = nullptr;
     bool last_split = false;
+    size_t last_parts[2] = {0, 0}; // queries in the two parts of the last search_dev call (second 0 = one part)
     int split_pm = 0; // permille of a large batch in its first part; 0 = one part (ivfhnsw_gpu_set_batch_split)
     bool visited_zero = false;        // every byte of w_visited is zero (the walk's overflow bitmaps, kernels_hnsw.hip)
     void *visited_zero_ptr = nullptr; // ... of this allocation
@@ -362,13 +363,15 @@ int ivfhnsw_gpu_device_count(int *count)
     return IVFHNSW_OK;
 }
 
+static const int kSplitAuto = 1000; // the first part's share follows the call's walk : table + plan + scan estimate
+
 static int split_permille_env()
 {
     static const int v = [] {
-        // on by default since round 3 (780 permille in the first part measured best); IVFHNSW_SPLIT=0 = one part
+        // on by default since round 3; IVFHNSW_SPLIT=0 = one part, 1..999 = that share in the first part, unset = by estimate
         const char *e = getenv("IVFHNSW_SPLIT");
-        const int x = (e && *e) ? atoi(e) : 780;
-        return (x > 0 && x < 1000) ? x : 0;
+        const int x = (e && *e) ? atoi(e) : kSplitAuto;
+        return (x > 0 && x <= kSplitAuto) ? x : 0;
     }();
     return v;
 }
@@ -1345,8 +1348,8 @@ int ivfhnsw_gpu_set_batch_split(ivfhnsw_gpu *h, int permille)
 {
     if (!h)
         return fail(IVFHNSW_ERR_INVALID, "null handle");
-    if (permille < 0 || permille >= 1000)
-        return fail(IVFHNSW_ERR_INVALID, "batch split %d outside 0..999 permille", permille);
+    if (permille < 0 || permille > kSplitAuto)
+        return fail(IVFHNSW_ERR_INVALID, "batch split %d outside 0..999 permille (1000 = by estimate)", permille);
     if (h->is_view && permille)
         return fail(IVFHNSW_ERR_INVALID, "a view cannot split its batches (it is what the second part runs on)");
     h->split_pm = permille;
@@ -1364,6 +1367,27 @@ int ivfhnsw_gpu_set_option(ivfhnsw_gpu *h, const char *key, long value)
         return IVFHNSW_OK;
     }
     return fail(IVFHNSW_ERR_INVALID, "set_option: unknown key '%s'", key);
+}
+
+// The first part's share when nobody fixed it.  The second part's walk fills the tail of the first part's, the first part's
+// table + plan + scan run beside the second part's walk, the second part's scan runs alone: the step is shortest where the
+// second walk and the first scan take equally long, share = W / (W + S).  W and S per query from the call's own parameters,
+// with rates measured at the 1B shapes on one MI355X: the walk 1.7 ns per unit of efSearch (1.37 / 1.63 /
+// 2.56 ms per 10 k queries at 80 / 100 / 130), the scan (M + 1) bytes per code at 5 TB/s over the codes the max_codes rule
+// lets through, the table 5 ns, the Grouping plan ~90 ns and its scan at 0.8 of the rate.  Measured against fixed shares:
+// (32, 10000, 80) 0.79 -> the 2048-query second part that measured best; (64, 30000, 100) 0.63 -> 4096, 3.97 -> 4.18 M
+// queries/s; Grouping + pruning 0.49 -> 4096, 3.35 -> 3.44 M.  The estimate only has to land on the right multiple of 2048.
+static int auto_split_permille(const ivfhnsw_gpu *h, const ivfhnsw_search_params *p)
+{
+    const double walk = 1.7 * (double)p->efSearch;
+    const double nc = (double)std::max<uint32_t>(h->t.nc, 1u);
+    const double list = (double)h->n_local / nc;
+    const double codes = std::min((double)p->nprobe * list, (double)p->max_codes + 0.5 * list);
+    double scan = codes * (double)(h->t.M + 1) / 5000.0 + 5.0;
+    if (h->has_group)
+        scan = scan / 0.8 + 90.0;
+    const double share = walk / (walk + scan);
+    return (int)std::min(900.0, std::max(400.0, share * 1000.0 + 0.5));
 }
 
 static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_queries, const ivfhnsw_search_params *p,
@@ -1391,7 +1415,8 @@ static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     // the second part: ~22 % of the batch, in whole "rounds" of the scan's resident workgroups (8 per CU x 256 CUs): its
     // scan runs alone at the end of the step, and 2200 workgroups on 2048 slots would take two rounds for one
     const size_t round_wgs = 2048;
-    size_t n2 = ((nq * (size_t)(1000 - h->split_pm) / 1000 + round_wgs / 2) / round_wgs) * round_wgs;
+    const int pm = h->split_pm == kSplitAuto ? auto_split_permille(h, p) : h->split_pm;
+    size_t n2 = ((nq * (size_t)(1000 - pm) / 1000 + round_wgs / 2) / round_wgs) * round_wgs;
     n2 = std::max(round_wgs, std::min(n2, nq / 2));
     const size_t n1 = nq - n2;
     const size_t d = (size_t)h->t.d;
@@ -1408,6 +1433,8 @@ static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     HIP_TRY(hipEventRecord(h->split_join, v->stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, h->split_join, 0));
     h->last_split = rc2 == 0;
+    h->last_parts[0] = n1;
+    h->last_parts[1] = n2;
     return rc2;
 }
 
@@ -1415,8 +1442,11 @@ static int search_dev_part(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_q
                            const float *d_coarse_dists, const ivfhnsw_search_params *p, float *d_distances,
                            int64_t *d_labels, int64_t *d_out_keys)
 {
-    if (h)
+    if (h) {
         h->last_split = false;
+        h->last_parts[0] = nq;
+        h->last_parts[1] = 0;
+    }
     const bool split = h && p && !h->is_view && h->split_pm > 0 && nq >= kSplitMinNq && !d_coarse_ids &&
                        !d_out_keys && !(p->heap_order && k > 1) && h->has_ivf && h->has_graph && p->nprobe > 0 && k > 0 &&
                        k <= 1024 && d_queries && d_distances && d_labels;
@@ -2148,6 +2178,17 @@ int ivfhnsw_gpu_last_scan_counts(ivfhnsw_gpu *h, uint64_t *ncodes, uint64_t *nse
 }
 
 const char *ivfhnsw_gpu_last_scan_kernel(ivfhnsw_gpu *h) { return h ? h->last_scan_kernel : ""; }
+
+int ivfhnsw_gpu_last_batch_parts(ivfhnsw_gpu *h, uint64_t *first, uint64_t *second)
+{
+    if (!h)
+        return fail(IVFHNSW_ERR_INVALID, "null handle");
+    if (first)
+        *first = h->last_parts[0];
+    if (second)
+        *second = h->last_parts[1];
+    return IVFHNSW_OK;
+}
 
 int ivfhnsw_gpu_memory_bytes(ivfhnsw_gpu *h, uint64_t *bytes)
 {

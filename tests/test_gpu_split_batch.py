@@ -59,3 +59,27 @@ def test_split_batch_equals_oracle(gpu, grouping):
     d5, l5 = g.search(c["queries"], 5, nprobe, max_codes, efSearch=ef, do_pruning=grouping)
     o = np.argsort(ref_d5, axis=1, kind="stable")
     assert np.array_equal(np.sort(d5, axis=1).view(np.uint32), np.take_along_axis(ref_d5, o, 1).view(np.uint32))
+
+
+def test_default_split_follows_the_parameters(gpu):
+    """A fresh handle cuts by estimate (ivfhnsw_gpu_set_batch_split 1000, the default): a walk-heavy call keeps the second
+    part at one 2048-query round, a scan-heavy one takes two -- and the results are the one-part call's either way."""
+    import os
+    if os.environ.get("IVFHNSW_SPLIT"):
+        pytest.skip("IVFHNSW_SPLIT fixes the share")
+    c = corpus(seed=73, nc=256, d=128, M=16, n_base=100000, nq=9000, efConstruction=60)
+    g = gpu()
+    _upload(g, c)
+    ox = synth.oracle_index(c)
+    for (nprobe, max_codes, ef), second in (((8, 200, 120), 2048), ((64, 60000, 64), 4096)):
+        ox.set_params(nprobe, max_codes, ef, do_pruning=False)
+        ref_d, ref_l, _, _, st = ox.search_batch(c["queries"], k=1)
+        hd, hl = g.search(c["queries"], 1, nprobe, max_codes, efSearch=ef)
+        assert g.last_batch_parts() == (9000 - second, second)
+        assert np.array_equal(hl, ref_l) and np.array_equal(hd.view(np.uint32), ref_d.view(np.uint32))
+        assert g.last_scan_counts()[0] == st.ncode
+    g.set_batch_split(0)
+    g.search(c["queries"], 1, 8, 200, efSearch=120)
+    assert g.last_batch_parts() == (9000, 0)
+    with pytest.raises(Exception):
+        g.set_batch_split(1001)
