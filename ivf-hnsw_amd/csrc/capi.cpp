@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <new>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -497,7 +498,7 @@ int ivfhnsw_gpu_sync(ivfhnsw_gpu *h)
 }
 
 int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
-{
+try {
     if (h && h->is_view)
         return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
@@ -523,10 +524,12 @@ int ivfhnsw_gpu_upload_ivf(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d)
     h->has_ivf = true;
     h->has_group = false;
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_upload_ivf: host allocation failed");
 }
 
 int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, uint64_t seed)
-{
+try {
     if (h && h->is_view)
         return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
@@ -557,11 +560,13 @@ int ivfhnsw_gpu_upload_ivf_synthetic(ivfhnsw_gpu *h, const ivfhnsw_ivf_desc *d, 
     h->has_ivf = true;
     h->has_group = false;
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_upload_ivf_synthetic: host allocation failed");
 }
 
 int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alphas, const uint32_t *nn_centroid_idxs,
                                 const uint32_t *subgroup_sizes, const float *inter_centroid_dists)
-{
+try {
     if (h && h->is_view)
         return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
@@ -628,6 +633,8 @@ int ivfhnsw_gpu_upload_grouping(ivfhnsw_gpu *h, size_t nsubc, const float *alpha
     }
     h->has_group = true;
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_upload_grouping: host allocation failed");
 }
 
 // The walk's exact rejection filter (kernels_hnsw.hip): one byte per component, x ~ lo + step * byte with one
@@ -719,7 +726,7 @@ static int build_neighbour_rows(ivfhnsw_gpu *h)
 
 int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM, uint32_t enterpoint,
                                  const uint8_t *link_counts, const uint32_t *links, const float *vectors)
-{
+try {
     if (h && h->is_view)
         return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
@@ -820,6 +827,8 @@ int ivfhnsw_gpu_upload_quantizer(ivfhnsw_gpu *h, size_t n, size_t d, size_t maxM
         return rc;
     h->has_graph = true;
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_upload_quantizer: host allocation failed");
 }
 
 int ivfhnsw_gpu_prepare_latency(ivfhnsw_gpu *h)
@@ -974,7 +983,7 @@ int ivfhnsw_gpu_coarse(ivfhnsw_gpu *h, size_t nq, const float *queries, size_t k
 // construction side
 int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, const float *pq_centroids,
                                  const float *norm_table, const float *opq_A)
-{
+try {
     if (h && h->is_view)
         return fail(IVFHNSW_ERR_STATE, "uploads go to the handle that holds the tables, not to a view of it");
     int rc = bind(h);
@@ -1004,6 +1013,8 @@ int ivfhnsw_gpu_upload_codebooks(ivfhnsw_gpu *h, size_t d, size_t code_size, con
     h->e_M = code_size;
     h->has_codebooks = true;
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_upload_codebooks: host allocation failed");
 }
 
 // residual against table[rows[i]] -> [OPQ] -> codes -> decode -> [OPQ back] -> + table row -> squared norm -> norm
@@ -1086,7 +1097,7 @@ int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, cons
                               const uint64_t *offsets, const float *x, size_t efSearch, uint32_t *out_nn_centroid_idxs,
                               float *out_alphas, uint32_t *out_subcentroid_idxs, uint8_t *out_codes,
                               uint8_t *out_norm_codes)
-{
+try {
     int rc = bind(h);
     if (rc)
         return rc;
@@ -1202,6 +1213,8 @@ int ivfhnsw_gpu_encode_groups(ivfhnsw_gpu *h, size_t ngroups, size_t nsubc, cons
         g0 = g1;
     }
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_encode_groups: host allocation failed");
 }
 
 int ivfhnsw_gpu_pq_train(ivfhnsw_gpu *h, size_t n, size_t d, size_t M, const float *x, size_t niter, float *centroids,
@@ -1335,8 +1348,8 @@ static const size_t kMaxBatchAll = 1 << 17;
 // last round frees, and the first part's table + scan (LDS-bound) run beside it (HBM-bound).  Fork and join are events,
 // so the call keeps its contract: everything is ordered behind the caller's stream and complete when that stream gets
 // there.  Measured (tools/split_probe.py, 1B corpus, 10 k queries): 1.81 -> 1.67 ms per batch, the first part's scan at
-// 4.8 instead of 5.0 TB/s; three parts give no more, four lose.  ON by default since round 3 (780 permille in the first
-// part; ivfhnsw_gpu_set_batch_split(h, 0) or IVFHNSW_SPLIT=0 = one part): a plain search_dev call should deliver the
+// 4.8 instead of 5.0 TB/s; three parts give no more, four lose.  ON by default since round 3 (the first part's share by
+// estimate, auto_split_permille; ivfhnsw_gpu_set_batch_split(h, 0) or IVFHNSW_SPLIT=0 = one part): a plain search_dev call should deliver the
 // fastest exact form.  The price is in the scan's accounting: two launches per step, the first slowed a little by the walk
 // beside it, the second a single round of workgroups -- 17 B x all codes over the summed launch time is 0.58-0.59 of the
 // HBM peak where the one-launch form reads 0.62 (bench.py reports both).  Not for sharded calls (their resolve step
@@ -1914,7 +1927,7 @@ std::vector<ncclComm_t> *rccl_comms(const std::vector<int> &devs)
 int ivfhnsw_gpu_search_sharded(ivfhnsw_gpu *const *shards, size_t nshards, size_t nq, size_t k, const float *queries,
                                const uint32_t *coarse_ids, const float *coarse_dists, const ivfhnsw_search_params *p,
                                float *distances, int64_t *labels)
-{
+try {
     if (!shards || nshards == 0 || nshards > 64)
         return fail(IVFHNSW_ERR_INVALID, "search_sharded: 1..64 shard handles");
     for (size_t r = 0; r < nshards; r++)
@@ -2053,6 +2066,8 @@ int ivfhnsw_gpu_search_sharded(ivfhnsw_gpu *const *shards, size_t nshards, size_
             labels[i] = (r == 0 || lab[i] > labels[i]) ? lab[i] : labels[i];
     }
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return fail(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_search_sharded: host allocation failed");
 }
 
 int ivfhnsw_gpu_resolve_keys(ivfhnsw_gpu *h, size_t nq, size_t k, const int64_t *keys, float *distances, int64_t *labels)

@@ -15,6 +15,7 @@
 #include "../../include/ivfhnsw_hip.h"
 
 #include <algorithm>
+#include <new>
 #include <cstdarg>
 #include <cstdint>
 #include <cstring>
@@ -107,11 +108,14 @@ template <class F> void parallel_for(size_t n, F f)
 
 extern "C" int ivfhnsw_gpu_build_graph(ivfhnsw_gpu *h, size_t n, size_t d, const float *vectors, size_t M, size_t maxM,
                                        size_t ncand, uint8_t *out_counts, uint32_t *out_links)
-{
+try {
     if (!h || !vectors || !out_counts || !out_links)
         return ivfhnsw_gpu_fail_msg(IVFHNSW_ERR_INVALID, "build_graph: null argument");
     if (M < 1 || M > maxM || maxM > 64 || ncand < M || ncand > 80 || n >= 0xffffffffull)
         return ivfhnsw_gpu_fail_msg(IVFHNSW_ERR_INVALID, "build_graph: need 1 <= M <= maxM <= 64, M <= ncand <= 80, n < 2^32");
+    if (d % 16 != 0)
+        return ivfhnsw_gpu_fail_msg(IVFHNSW_ERR_INVALID, "build_graph: d must be a multiple of 16 (the reference's distance "
+                                                         "ignores the dims beyond one, hnswalg.cpp:330; so does upload_quantizer)");
     std::memset(out_counts, 0, n);
     std::memset(out_links, 0, n * maxM * sizeof(uint32_t));
     if (n <= 1)
@@ -179,4 +183,6 @@ extern "C" int ivfhnsw_gpu_build_graph(ivfhnsw_gpu *h, size_t n, size_t d, const
         out_counts[t] = (uint8_t)cnt;
     });
     return IVFHNSW_OK;
+} catch (const std::bad_alloc &) {
+    return ivfhnsw_gpu_fail_msg(IVFHNSW_ERR_NOMEM, "ivfhnsw_gpu_build_graph: host allocation failed");
 }

@@ -115,6 +115,9 @@ def test_options_and_neighbour_table_arguments_are_checked(gpu, pkg):
         g.build_graph(x, M=16, maxM=8)          # M > maxM
     with pytest.raises(pkg.IvfHnswError):
         g.build_graph(x, M=16, maxM=32, ncand=100)
+    with pytest.raises(pkg.IvfHnswError) as e:
+        g.build_graph(np.zeros((40, 24), np.float32), M=8, maxM=16, ncand=16)   # the reference's distance stops at d - d % 16
+    assert e.value.code == pkg.ERR_INVALID and "multiple of 16" in str(e.value)
     # the handle is still usable
     ids, _ = g.knn(x + np.arange(40, dtype=np.float32)[:, None], 3)
     assert ids.shape == (40, 3)
