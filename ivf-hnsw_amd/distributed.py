@@ -211,7 +211,7 @@ class ShardedSearcher:
         self.parts = None
         if split is None:
             split = 780 if world < 8 else 600
-        if (split and k == 1 and self.device.type == "cuda" and world > 1 and nq % world == 0 and self.per >= split_min
+        if (split and k == 1 and self.device.type == "cuda" and self.collectives and nq % world == 0 and self.per >= split_min
                 and hasattr(gpu_index, "view")):
             per = self.per
             n2 = ((per * (1000 - split) // 1000 + 1024) // 2048) * 2048

@@ -1,6 +1,6 @@
 """The RCCL calls of the multi-GPU step, executed: a single-rank `nccl` (= RCCL) process group accepts every collective
 ShardedSearcher.step issues -- all-gather of the coarse stage, int64 MIN all-reduce of the packed keys, int64 MAX of the
-labels, all-gather of the k > 1 keys and of the candidate streams -- so a one-GPU box can run the very code path the
+labels, all-gather of the k > 1 keys and of the candidate streams, and the two-part step on a view and a side stream -- so a one-GPU box can run the very code path the
 8-GPU node takes (dtypes, shapes, in-place semantics), with results checked against the oracle.  What it cannot show is
 the exchange between ranks: that is tests/test_distributed_cpu.py (gloo, world 2 / 3) and tools/rehearse_ranks.sh."""
 import os
@@ -53,6 +53,22 @@ for nsubc in (0, 8):
             assert np.array_equal(dis.view(np.uint32), ref_d.view(np.uint32)), (nsubc, k, heap)
         else:
             assert np.array_equal(np.sort(lab, 1), np.sort(ref_l, 1)) and (np.diff(dis, axis=1) >= 0).all()
+    # the two-part step (the default of a rank whose slice is >= 8192 queries): part 2 on a view and a side stream, the
+    # all-gathers of both parts, ONE MIN and ONE MAX all-reduce -- the same calls on RCCL
+    nqb = 4096
+    qb = np.ascontiguousarray(np.tile(c["queries"], (nqb // nq + 1, 1))[:nqb] + np.float32(0.5) * (np.arange(nqb, dtype=np.float32)[:, None] %% 5))
+    rdb, rlb, _, _, stb = ox.search_batch(qb, k=1)
+    d_qb = torch.from_numpy(qb).to(dev)
+    ddb = torch.empty((nqb, 1), dtype=torch.float32, device=dev)
+    llb = torch.empty((nqb, 1), dtype=torch.int64, device=dev)
+    s2 = D.ShardedSearcher(g, 0, 1, nqb, nprobe, dev, k=1, force_collectives=True, split_min=4096)
+    assert s2.parts is not None and [p["n"] for p in s2.parts] == [2048, 2048]
+    for _ in range(2):
+        s2.step(d_qb, ddb, llb, max_codes, ef, do_pruning=bool(nsubc))
+    torch.cuda.synchronize()
+    assert np.array_equal(llb.cpu().numpy(), rlb) and np.array_equal(ddb.cpu().numpy().view(np.uint32), rdb.view(np.uint32)), nsubc
+    assert s2.last_scan_counts()[0] == stb.ncode
+    s2.close()
     g.close()
 dist.barrier()
 dist.destroy_process_group()
