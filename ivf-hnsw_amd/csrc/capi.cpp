@@ -134,8 +134,10 @@ struct ivfhnsw_gpu {
     ivfhnsw_gpu *split_view = nullptr;
     hipEvent_t split_fork = nullptr, split_join = nullptr;
     bool last_split = false;
+    uint32_t *status_shared = nullptr; // the internal split view raises its status bits in the PARENT's word (no merge launch)
     size_t last_parts[2] = {0, 0}; // queries in the two parts of the last search_dev call (second 0 = one part)
     int split_pm = 0; // permille of a large batch in its first part; 0 = one part (ivfhnsw_gpu_set_batch_split)
+    bool walk_counters_clean = true;  // w_status[1..4] are zero (ivfhnsw_gpu_create clears them, the redo launch's last wavefront restores it)
     bool visited_zero = false;        // every byte of w_visited is zero (the walk's overflow bitmaps, kernels_hnsw.hip)
     void *visited_zero_ptr = nullptr; // ... of this allocation
     size_t visited_zero_bytes = 0;
@@ -173,6 +175,9 @@ int bind(ivfhnsw_gpu *h)
     HIP_TRY(hipSetDevice(h->device));
     return IVFHNSW_OK;
 }
+
+// the word the kernels of this handle raise status bits in
+inline uint32_t *status_word(ivfhnsw_gpu *h) { return h->status_shared ? h->status_shared : h->w_status.as<uint32_t>(); }
 
 int upload(DevBuf &b, const void *src, size_t bytes)
 {
@@ -403,8 +408,8 @@ int ivfhnsw_gpu_create(int device, ivfhnsw_gpu **out)
     }
     h->own_stream = true;
     h->split_pm = split_permille_env();
-    // [0] status bits, [1] the walk's query counter, [2] queries on the redo list, [3] the redo launch's counter
-    if (h->w_status.ensure(4 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 4 * sizeof(uint32_t)) != hipSuccess) {
+    // [0] status bits, [1] the walk's query counter, [2] queries on the redo list, [3] the redo launch's counter, [4] its exit count
+    if (h->w_status.ensure(8 * sizeof(uint32_t)) || hipMemset(h->w_status.p, 0, 8 * sizeof(uint32_t)) != hipSuccess) {
         ivfhnsw_gpu_destroy(h);
         return fail(IVFHNSW_ERR_HIP, "cannot allocate the device status word");
     }
@@ -904,17 +909,17 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         if (!defer) {
             if ((rc = walk_scratch(64, &tails)))
                 return rc;
-            HIP_TRY(hipMemsetAsync(hdr, 0, 2 * sizeof(uint32_t), h->stream));
+            HIP_TRY(hipMemsetAsync(hdr, 0, 3 * sizeof(uint32_t), h->stream)); // length, counter, exit count
         }
         HIP_TRY(launch_coarse_latency(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                                      d_coarse_dists, h->w_status.as<uint32_t>(), h->walk_zero_keys, h->walk_zero_done,
+                                      d_coarse_dists, status_word(h), h->walk_zero_keys, h->walk_zero_done,
                                       defer ? nullptr : hdr, defer ? nullptr : h->w_redo.as<uint32_t>()));
         h->walk_zeroed = h->walk_zero_keys != nullptr;
         h->walk_zero_keys = nullptr; // consumed: set by search_dev right before the call, never carried over
         h->walk_zero_done = nullptr;
         if (!defer)
             HIP_TRY(launch_coarse_redo(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                                       d_coarse_dists, h->w_visited.as<uint32_t>(), words, h->w_status.as<uint32_t>(), hdr,
+                                       d_coarse_dists, h->w_visited.as<uint32_t>(), words, status_word(h), hdr,
                                        h->w_redo.as<uint32_t>(), tails, 64));
         return IVFHNSW_OK;
     }
@@ -923,9 +928,9 @@ int ivfhnsw_gpu_coarse_dev(ivfhnsw_gpu *h, size_t nq, const float *d_queries, si
         if ((rc = walk_scratch((size_t)nslots, &tails)))
             return rc;
         HIP_TRY(launch_coarse(h->stream, h->gr, d_queries, (int)nq, (int)nprobe, (int)efSearch, d_coarse_ids,
-                              d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, h->w_status.as<uint32_t>(),
+                              d_coarse_dists, h->w_visited.as<uint32_t>(), words, nslots, status_word(h),
                               h->w_status.as<uint32_t>() + 1, h->w_visited.bytes / 2, &h->visited_zero,
-                              h->w_redo.as<uint32_t>(), tails, 64));
+                              h->w_redo.as<uint32_t>(), tails, 64, &h->walk_counters_clean));
     }
     return IVFHNSW_OK;
 }
@@ -1425,6 +1430,7 @@ static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     v->gr = h->gr;
     v->has_graph = h->has_graph;
     v->profiling = h->profiling;
+    v->status_shared = h->w_status.as<uint32_t>();
     // the second part: ~22 % of the batch, in whole "rounds" of the scan's resident workgroups (8 per CU x 256 CUs): its
     // scan runs alone at the end of the step, and 2200 workgroups on 2048 slots would take two rounds for one
     const size_t round_wgs = 2048;
@@ -1439,10 +1445,9 @@ static int search_dev_split(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
     int rc2 = rc ? rc
                  : search_dev_chunk(v, nq - n1, k, d_queries + n1 * d, nullptr, nullptr, p, d_distances + n1 * k,
                                     d_labels + n1 * k, nullptr);
-    // whatever the second part flagged joins the handle's status word; the join itself, always (the fork was recorded)
+    // (whatever the second part flags it raises in the handle's own status word: v->status_shared)
+    // the join itself, always (the fork was recorded)
     (void)hipSetDevice(h->device);
-    if (!rc2)
-        (void)launch_status_merge(v->stream, v->w_status.as<uint32_t>(), h->w_status.as<uint32_t>());
     HIP_TRY(hipEventRecord(h->split_join, v->stream));
     HIP_TRY(hipStreamWaitEvent(h->stream, h->split_join, 0));
     h->last_split = rc2 == 0;
@@ -1581,7 +1586,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
             HIP_TRY(hipMemsetAsync(h->w_tail.p, 0, tail_kbytes + nq * sizeof(uint32_t), h->stream));
         HIP_TRY(launch_ivf_tail(h->stream, h->t, xq, cid, cd, (int)nq, nprobe, p->max_codes, nsplit,
                                 h->w_tail.as<uint64_t>(), reinterpret_cast<uint32_t *>(h->w_tail.as<char>() + tail_kbytes),
-                                h->w_hdr.as<PlanHdr>(), d_distances, d_labels, h->w_status.as<uint32_t>(),
+                                h->w_hdr.as<PlanHdr>(), d_distances, d_labels, status_word(h),
                                 h->tail_status_out));
         h->tail_wrote_status = h->tail_status_out != nullptr;
         h->last_scan_kernel = "ivf_tail_kernel";
@@ -1672,7 +1677,7 @@ static int search_dev_chunk(ivfhnsw_gpu *h, size_t nq, size_t k, const float *d_
         if (heap && !d_out_keys)
             HIP_TRY(launch_heap_replay(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
                                        h->w_stream.as<uint64_t>(), h->w_slen.as<uint32_t>(), kHeapStreamCap, (int)nq,
-                                       (int)k, d_distances, d_labels, h->w_status.as<uint32_t>(), nullptr));
+                                       (int)k, d_distances, d_labels, status_word(h), nullptr));
         else
             HIP_TRY(launch_select(h->stream, h->t, h->w_segs.as<Seg>(), h->w_hdr.as<PlanHdr>(), max_seg,
                                   h->w_keys.as<uint64_t>(), (int)nq, (int)k, d_distances, d_labels, d_out_keys));
@@ -1732,7 +1737,7 @@ int ivfhnsw_gpu_replay_stream_dev(ivfhnsw_gpu *h, size_t nq, size_t k, const uin
         return fail(IVFHNSW_ERR_INVALID, "bad replay_stream arguments (k %zu)", k);
     StageScope sc(h, IVFHNSW_STAGE_SELECT);
     HIP_TRY(launch_heap_replay(h->stream, h->t, nullptr, nullptr, 0, d_stream, d_len, cap, (int)nq, (int)k, nullptr,
-                               nullptr, h->w_status.as<uint32_t>(), d_out_keys));
+                               nullptr, status_word(h), d_out_keys));
     return IVFHNSW_OK;
 }
 

@@ -122,8 +122,6 @@ hipError_t launch_opq(hipStream_t s, const float *At, const float *x, float *y, 
 // tab[q][m][c] = <x_m, centroid[m][c]>  (IndexIVF_HNSW.cpp:262)
 // hdr (optional): queries whose plan is empty on this shard get no table
 hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq, const PlanHdr *hdr = nullptr);
-// *dst |= *src; *src = 0 (the status word of a split batch's second part joins the handle's)
-hipError_t launch_status_merge(hipStream_t s, uint32_t *src, uint32_t *dst);
 // probe order + max_codes rule (IndexIVF_HNSW.cpp:267-292); also resets keys[nq*k] to kKeyInit
 hipError_t launch_plan_ivf(hipStream_t s, const IvfTables &t, const uint32_t *coarse_ids,
                            const float *coarse_dists, int nq, int nprobe, uint64_t max_codes, Seg *segs,
@@ -173,9 +171,12 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g, const float *xq, i
                          size_t visited_bytes = 0, bool *visited_zero = nullptr, // in/out: the whole scratch is zero
                          // queries the fast form cannot finish (> 64 exact ties at the efSearch boundary) are listed in
                          // redo_list [nq] and walked again by launch_coarse_redo, which launch_coarse ends with;
-                         // next_query must be followed by two more words (the list's header); tail_bitmaps
-                         // [tail_slots][words] zero on entry and on exit (walk_set.h TailSpill)
-                         uint32_t *redo_list = nullptr, uint32_t *tail_bitmaps = nullptr, int tail_slots = 0);
+                         // next_query must be followed by three more words (the list's header: length, the redo
+                         // launch's counter, its exit count); tail_bitmaps [tail_slots][words] zero on entry and on
+                         // exit (walk_set.h TailSpill).  counters_clean (in/out): the four words are zero -- the redo
+                         // launch's last wavefront leaves them so, and the launcher then skips its memset
+                         uint32_t *redo_list = nullptr, uint32_t *tail_bitmaps = nullptr, int tail_slots = 0,
+                         bool *counters_clean = nullptr);
 hipError_t launch_coarse_redo(hipStream_t s, const GraphTables &g, const float *xq, int nq, int nprobe, int ef,
                               uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
                               size_t visited_words_per_slot, uint32_t *status, uint32_t *redo_hdr, uint32_t *redo_list,

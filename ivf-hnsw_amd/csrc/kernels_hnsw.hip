@@ -884,6 +884,20 @@ __global__ __launch_bounds__(64, MINW) void hnsw_walk_kernel(GraphTables g, cons
             }
         }
     }
+    if constexpr (SPILL) {
+        // The last wavefront out leaves the walk's counters as the next launch expects them -- the fast form's query
+        // counter (the word before the header), the list's length, this launch's own counter and the exit count itself --
+        // so that launches need no memset between them (it was ~8 us of every step's critical path).
+        if (lane == 0) {
+            __threadfence();
+            if (atomicAdd(&redo_hdr[2], 1u) == gridDim.x - 1) {
+                redo_hdr[-1] = 0;
+                redo_hdr[0] = 0;
+                redo_hdr[1] = 0;
+                redo_hdr[2] = 0;
+            }
+        }
+    }
     if (SPILL && redo_ran) { // the redo form runs on bitmap-only visited sets inside scratch the fast forms expect to find zero
         uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
         for (size_t w = lane; w < vwords / 4; w += 64)
@@ -961,7 +975,7 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
                          uint32_t *coarse_ids, float *coarse_dists, uint32_t *visited_scratch,
                          size_t visited_words_per_slot, int nslots, uint32_t *status, uint32_t *next_query,
                          size_t visited_bytes, bool *visited_zero, uint32_t *redo_list, uint32_t *tail_bitmaps,
-                         int tail_slots)
+                         int tail_slots, bool *counters_clean)
 {
     if (nq == 0)
         return hipSuccess;
@@ -969,11 +983,18 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
     if (ef > 1024 || ef < 1 || nprobe > ef || g.maxM > 64 || g.n >= 0x80000000u || (visited_words_per_slot & 3) ||
         !redo_list || !tail_bitmaps || tail_slots < 1)
         return hipErrorInvalidValue;
-    // next_query, and behind it the redo list's header (number of listed queries, the redo launch's counter)
+    // next_query, and behind it the redo list's header (number of listed queries, the redo launch's counter, the redo
+    // launch's exit count).  All four are zero between launches: the redo launch's last wavefront clears them; only a
+    // handle that cannot vouch for that (first use, a failed launch) pays a memset.
     uint32_t *redo_hdr = next_query + 1;
-    hipError_t e = hipMemsetAsync(next_query, 0, 3 * sizeof(uint32_t), s);
-    if (e != hipSuccess)
-        return e;
+    hipError_t e = hipSuccess;
+    if (!counters_clean || !*counters_clean) {
+        e = hipMemsetAsync(next_query, 0, 4 * sizeof(uint32_t), s);
+        if (e != hipSuccess)
+            return e;
+    }
+    if (counters_clean)
+        *counters_clean = false;
     // Waves per SIMD the kernel is built for (register budget and visited-set size follow from it).  Measured
     // on MI355X (100M / 2^17-centroid workload, ef 80) with the LDS padded to hold 2, 3, 4 waves per SIMD
     // resident: 2.61, 1.90, 1.54 ms per 10 k queries = 0.48 + 4.26 / waves -- the walk is latency bound per wave.
@@ -1101,8 +1122,11 @@ hipError_t launch_coarse(hipStream_t s, const GraphTables &g_in, const float *xq
     e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    return launch_coarse_redo(s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot,
-                              status, redo_hdr, redo_list, tail_bitmaps, tail_slots);
+    e = launch_coarse_redo(s, g, xq, nq, nprobe, ef, coarse_ids, coarse_dists, visited_scratch, visited_words_per_slot,
+                           status, redo_hdr, redo_list, tail_bitmaps, tail_slots);
+    if (e == hipSuccess && counters_clean)
+        *counters_clean = true;
+    return e;
 }
 
 // The queries a fast form of the walk (this file's, or the latency form of kernels_hnsw_lat.hip) could not finish: more

@@ -153,21 +153,6 @@ __global__ __launch_bounds__(256) void lut_kernel(const float *__restrict__ xq, 
     lut_body<DSUB>((int)blockIdx.x, s_q, xq, cb, luts, nq, d, M, dsub_rt, hdr);
 }
 
-__global__ void status_merge_kernel(uint32_t *src, uint32_t *dst)
-{
-    const uint32_t v = *src;
-    if (v) {
-        atomicOr(dst, v);
-        *src = 0;
-    }
-}
-
-hipError_t launch_status_merge(hipStream_t s, uint32_t *src, uint32_t *dst)
-{
-    hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(1), 0, s, src, dst);
-    return hipGetLastError();
-}
-
 hipError_t launch_lut(hipStream_t s, const IvfTables &t, const float *xq, float *luts, int nq, const PlanHdr *hdr)
 {
     if (nq == 0)
