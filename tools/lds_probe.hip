@@ -83,5 +83,9 @@ int main()
     pat("random, lanes confined to 16-bank groups by l/16 (64 banks)", [](int l) { int r = l / 16; return (rand() % 32) * 64 + r * 16 + rand() % 16; });
     pat("random, 4-bank groups by l/4 (64 banks)", [](int l) { int r = l / 4; return (rand() % 32) * 64 + r * 4 + rand() % 4; });
     pat("random over 64 banks (dword in 64-wide rows)", [](int) { return (rand() % 32) * 64 + rand() % 64; });
+    // the lane IS the sub-quantizer (systolic ADC): table m = l % 16 pinned to banks {m, m + 16} by the code's low bit
+    pat("table per lane: 16*c + l%16, c random (2 lanes per bank pair)", [](int l) { return 16 * (rand() % 256) + (l % 16); });
+    // ... and with a second query's tables in banks 16..31 (lanes 16..31 of each half): one lane per bank
+    pat("table per lane: 32*c + l%32, c random (conflict free)", [](int l) { return 32 * (rand() % 256) + (l % 32); });
     return 0;
 }
